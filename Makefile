@@ -1,0 +1,36 @@
+# Builds the C-ABI HIP library for gfx950 (cross-compiles without a GPU).
+#   make            -> scene-net_amd/lib/libscenenet_hip.so
+#   make asm        -> build/*.s + resource usage (VGPR/LDS/occupancy) for inspection
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+PKG      := scene-net_amd
+SRC      := $(PKG)/csrc
+OUT      := $(PKG)/lib
+OBJDIR   := build/obj
+CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wall -Wno-unused-function
+# voxel.hip reproduces numpy's fp64 rounding sequence: never contract a*b+c
+FLAGS_voxel := -ffp-contract=off
+
+SOURCES := cabi bank voxel conv
+OBJS    := $(SOURCES:%=$(OBJDIR)/%.o)
+
+all: $(OUT)/libscenenet_hip.so
+
+$(OBJDIR)/%.o: $(SRC)/%.hip $(SRC)/common.h include/scenenet_hip.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(CXXFLAGS) $(FLAGS_$*) -c $< -o $@
+
+$(OUT)/libscenenet_hip.so: $(OBJS)
+	@mkdir -p $(OUT)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+
+asm:
+	@mkdir -p build/asm
+	for f in $(SOURCES); do \
+	  $(HIPCC) $(CXXFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage \
+	    $(SRC)/$$f.hip -o build/asm/$$f.s 2> build/asm/$$f.usage.txt || exit 1; done
+
+clean:
+	rm -rf build $(OUT)
+
+.PHONY: all asm clean

@@ -1,0 +1,146 @@
+/*
+ * scenenet_hip.h -- C ABI of the MI355X-native SCENE-Net GENEO forward path.
+ *
+ * The reference (dlavado/scene-net) is pure Python and has no FFI layer; its
+ * "operator API" for this path is a set of Python classes/functions.  Each
+ * entry point below names the reference interface it replaces (file:line,
+ * relative to the reference tree).  INTEGRATION.md shows the ctypes stub a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain `extern "C"`, no torch / C++ types in any signature;
+ *   - every pointer is a caller-allocated DEVICE pointer (e.g. tensor.data_ptr())
+ *     unless the parameter name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on it (no allocation, no sync, graph-capturable);
+ *   - return value: 0 = SN_OK, negative = sn_status; sn_last_error() gives the
+ *     message of the calling thread's last failure;
+ *   - grids are [B, C, Z, X, Y] row-major, y fastest (utils/voxelization.py:193);
+ *     GENEO kernels are [G, kz, kx, ky] row-major.
+ */
+#ifndef SCENENET_HIP_H
+#define SCENENET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sn_stream_t;
+
+typedef enum {
+    SN_OK = 0,
+    SN_ERR_INVALID_ARG = -1,   /* null pointer, non-positive extent, bad enum        */
+    SN_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for       */
+    SN_ERR_LAUNCH = -3,        /* hipGetLastError() after a launch                   */
+    SN_ERR_NO_DEVICE = -4      /* no gfx950 device / HIP runtime unusable            */
+} sn_status;
+
+typedef enum { SN_F32 = 0, SN_F64 = 1, SN_U8 = 2 } sn_dtype;
+
+/* GENEO kinds, in SceneNet's key order (core/models/SCENE_Net.py:259-272). */
+typedef enum { SN_GENEO_CY = 0, SN_GENEO_CONE = 1, SN_GENEO_NEG = 2 } sn_geneo_kind;
+
+/* Parameter slots of one GENEO: params[g * SN_NPARAM + slot] (fp32). */
+enum {
+    SN_P_RADIUS = 0,      /* cy, cone, neg : cylinder.py:55, arrow.py:78, neg_sphere.py:62 */
+    SN_P_SIGMA = 1,       /* cy, cone, neg : default 1                                      */
+    SN_P_APEX = 2,        /* cone          : truncated to int, arrow.py:235                 */
+    SN_P_CONE_RADIUS = 3, /* cone          : arrow.py:84-87                                 */
+    SN_P_CONE_INC = 4,    /* cone          : clamped to [0, 0.499], arrow.py:244            */
+    SN_P_NEG_FACTOR = 5,  /* neg           : neg_sphere.py:63                               */
+    SN_NPARAM = 8
+};
+
+int sn_version(void);
+const char* sn_last_error(void);
+
+/* Number of gfx950 devices visible (0 when none); never throws. */
+int sn_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * K2  GENEO bank builder
+ * replaces: GENEO_Layer.compute_kernel (core/models/SCENE_Net.py:103-106) over
+ *           cylinderv2.compute_kernel (core/models/geneos/cylinder.py:162-176),
+ *           arrow.compute_kernel      (core/models/geneos/arrow.py:228-252),
+ *           negSpherev2.compute_kernel(core/models/geneos/neg_sphere.py:185-199)
+ *           and the torch.stack at SCENE_Net.py:324.
+ * params [G, SN_NPARAM] f32, kinds [G] i32 -> bank [G, kz, kx, ky] f32.
+ * status (nullable) [G] i32: 0 ok, 1 = int(apex) outside [0, kz] (the reference
+ * raises from torch.stack there; the kernel clamps and flags).
+ * ------------------------------------------------------------------------- */
+int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
+                  float* bank, int32_t* status, sn_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * K3  GENEO bank convolution + convex-combination head
+ * replaces: SceneNet.forward (core/models/SCENE_Net.py:322-339):
+ *           F.conv3d(x, kernels, padding='same') (cross-correlation, zero pad
+ *           left (k-1)/2, right k/2), sum_i lambda_i * conv_i, relu(tanh(.)).
+ * x [B,1,Z,X,Y] of x_dtype; bank [G,kz,kx,ky] f32; lambdas [G] f32 = the
+ * EFFECTIVE coefficients (last one already 1 - sum(others)), nullable iff out
+ * is null.  act (nullable) [B,G,Z,X,Y] and out (nullable) [B,1,Z,X,Y] are of
+ * out_dtype (SN_F32 or SN_F64).  fp32 MFMA accumulation.
+ * G <= 16 per call in this revision.
+ * ------------------------------------------------------------------------- */
+int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lambdas,
+                 int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
+                 void* act, void* out, int out_dtype, sn_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * K1  point cloud -> voxel grid
+ * replaces: pyntcloud VoxelGrid.compute as called by eda.voxelize_ply
+ *           (utils/pcd_processing.py:341-372), hist_on_voxel
+ *           (utils/voxelization.py:164-204), reg_on_voxel (:244-300),
+ *           normalize_xyz (utils/pcd_processing.py:305-321) and
+ *           ToFullDense.densify (core/datasets/torch_transforms.py:33-34).
+ *
+ * A batch is ragged: pts [total,3] f64 (x,y,z), labels [total] f64 (nullable),
+ * offsets [B+1] i64 (CSR: tile b owns points offsets[b] .. offsets[b+1]-1).
+ * ------------------------------------------------------------------------- */
+
+/* doubles per tile in a grid descriptor: lo[3], hi[3], then the linspace edge
+ * tables of x (nx+1), y (ny+1), z (nz+1). */
+#define SN_DESC_LEN(nx, ny, nz) (6 + (nx) + (ny) + (nz) + 3)
+
+/* Per-tile bounding box: bbox [B,6] f64 = (min x,y,z, max x,y,z). */
+int sn_voxel_bbox(const double* pts, const int64_t* offsets, int B, double* bbox, sn_stream_t stream);
+
+/* Grid descriptor from a bounding box, n_x/n_y/n_z mode
+ * (add_structure("voxelgrid", n_x, n_y, n_z), pcd_processing.py:362-363):
+ * regular != 0 pads the box to a cube (pyntcloud regular_bounding_box=True);
+ * edges are numpy.linspace(lo, hi, n+1) bit for bit.  desc [B, SN_DESC_LEN]. */
+int sn_voxel_desc(const double* bbox, int B, int nx, int ny, int nz, int regular,
+                  double* desc, sn_stream_t stream);
+
+/* Same, from explicit per-tile bounds [B,6] (lo xyz, hi xyz) the caller has
+ * already extended -- used for the size_x/size_y/size_z mode
+ * (pcd_processing.py:365-367), whose grid extents are data dependent. */
+int sn_voxel_desc_from_bounds(const double* bounds, int B, int nx, int ny, int nz,
+                              double* desc, sn_stream_t stream);
+
+/* Atomic scatter: counts[b,z,x,y] += 1 per point; tower_counts (nullable) += 1
+ * per point whose label equals one of keep_labels_host[0..n_keep) (<= 16).
+ * Both grids [B,nz,nx,ny] i32 are zeroed by the call.
+ * dropped (nullable) [B] i32: points that fall outside the edge table. */
+int sn_voxel_scatter(const double* pts, const double* labels, const int64_t* offsets, int B,
+                     const double* desc, int nx, int ny, int nz,
+                     int32_t* counts, int32_t* tower_counts,
+                     const double* keep_labels_host, int n_keep,
+                     int32_t* dropped, sn_stream_t stream);
+
+/* counts -> outputs (each nullable):
+ *   density [B,1,nz,nx,ny] f64 : hist_on_voxel's per-y-column min-max normalised counts
+ *   gt      [B,1,nz,nx,ny] f64 : reg_on_voxel's tower/total ratio (needs tower_counts)
+ *   occ     [B,1,nz,nx,ny] f32 : ToFullDense(density)  == (density > 0)
+ *   gt_occ  [B,1,nz,nx,ny] f32 : ToFullDense(gt)       == (tower > 0)
+ * colstats: workspace [B, 2, ny] i32. */
+int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_counts, int B, int nx, int ny, int nz,
+                      int32_t* colstats, double* density, double* gt, float* occ, float* gt_occ,
+                      sn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCENENET_HIP_H */

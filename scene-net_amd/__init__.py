@@ -1,0 +1,17 @@
+"""scene-net_amd -- MI355X-native SCENE-Net GENEO forward path (voxelise -> GENEO bank -> 3D conv -> head).
+
+Only what the hot path needs: `csrc/` (hand-written HIP for gfx950 behind the C ABI of
+include/scenenet_hip.h) and the host-side mirror of the reference's operator interface.
+Import as `scene_net_amd` (shim package at the repo root).
+"""
+from . import _hip
+from ._hip import HipLibraryError, LIB_PATH
+from .geneos import GENEO_kernel_torch, arrow, cylinderv2, negSpherev2
+from .scene_net import GENEO_Layer, SceneNet
+from .transforms import ToFullDense, ToTensor, Voxelization
+from .voxelization import PointBatch, VoxelGrids, hist_on_voxel, prob_to_label, reg_on_voxel, voxelize_batch
+from .pipeline import ScenePipeline, shard_range
+
+__all__ = ["SceneNet", "GENEO_Layer", "GENEO_kernel_torch", "cylinderv2", "arrow", "negSpherev2", "Voxelization",
+           "ToTensor", "ToFullDense", "hist_on_voxel", "reg_on_voxel", "prob_to_label", "voxelize_batch",
+           "PointBatch", "VoxelGrids", "ScenePipeline", "shard_range", "HipLibraryError", "LIB_PATH"]

@@ -1,0 +1,184 @@
+"""ctypes binding of the C-ABI HIP library (include/scenenet_hip.h).
+
+There is NO CPU fallback: if the library is missing or a tensor is not on a HIP
+device, the call raises.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_void_p
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscenenet_hip.so")
+
+SN_F32, SN_F64, SN_U8 = 0, 1, 2
+SN_GENEO_CY, SN_GENEO_CONE, SN_GENEO_NEG = 0, 1, 2
+SN_P_RADIUS, SN_P_SIGMA, SN_P_APEX, SN_P_CONE_RADIUS, SN_P_CONE_INC, SN_P_NEG_FACTOR = 0, 1, 2, 3, 4, 5
+SN_NPARAM = 8
+
+# every symbol include/scenenet_hip.h declares: (restype, argtypes)
+_P, _I = c_void_p, c_int
+SYMBOLS = {
+    "sn_version": (c_int, []),
+    "sn_last_error": (c_char_p, []),
+    "sn_device_count": (c_int, []),
+    "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
+    "sn_voxel_desc": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "sn_voxel_desc_from_bounds": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "sn_voxel_scatter": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "sn_voxel_finalize": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads libscenenet_hip.so (built by `make` / __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `make` or __graft_entry__.build()). "
+            "There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sn_last_error()
+        raise HipLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if not t.is_contiguous():
+        raise HipLibraryError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise HipLibraryError(f"{name} must be {dtype} (got {t.dtype})")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_DT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8}
+
+
+# --------------------------------------------------------------------------- #
+def geneo_bank(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int],
+               status: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """params [G, SN_NPARAM] f32, kinds [G] i32 -> bank [G, kz, kx, ky] f32 (sn_geneo_bank)."""
+    G = params.shape[0]
+    kz, kx, ky = (int(k) for k in kernel_size)
+    if out is None:
+        out = torch.empty((G, kz, kx, ky), dtype=torch.float32, device=params.device)
+    rc = load().sn_geneo_bank(_ptr(params, torch.float32, "params"), _ptr(kinds, torch.int32, "kinds"), G, kz, kx, ky,
+                              _ptr(out, torch.float32, "bank"), _ptr(status, torch.int32, "status"), _stream())
+    _check(rc, "sn_geneo_bank")
+    return out
+
+
+def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tensor], want_act: bool = False,
+              want_out: bool = True, out_dtype: Optional[torch.dtype] = None):
+    """x [B,1,Z,X,Y] (f32|f64|u8), bank [G,kz,kx,ky] f32, lambdas [G] f32 (effective) ->
+    (act [B,G,Z,X,Y] | None, out [B,1,Z,X,Y] | None) of out_dtype (sn_conv_bank)."""
+    if x.dim() != 5 or x.shape[1] != 1:
+        raise HipLibraryError(f"x must be [B,1,Z,X,Y] (got {tuple(x.shape)})")
+    if x.dtype not in _DT:
+        raise HipLibraryError(f"x dtype {x.dtype} unsupported (f32, f64, u8)")
+    B, _, Z, X, Y = x.shape
+    G, kz, kx, ky = bank.shape
+    if out_dtype is None:
+        out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
+    act = torch.empty((B, G, Z, X, Y), dtype=out_dtype, device=x.device) if want_act else None
+    out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device) if want_out else None
+    rc = load().sn_conv_bank(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                             _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky,
+                             _ptr(act, None, "act"), _ptr(out, None, "out"), _DT[out_dtype], _stream())
+    _check(rc, "sn_conv_bank")
+    return act, out
+
+
+def desc_len(nx: int, ny: int, nz: int) -> int:
+    return 6 + nx + ny + nz + 3
+
+
+def voxel_bbox(pts: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    B = offsets.numel() - 1
+    bbox = torch.empty((B, 6), dtype=torch.float64, device=pts.device)
+    rc = load().sn_voxel_bbox(_ptr(pts, torch.float64, "pts"), _ptr(offsets, torch.int64, "offsets"), B,
+                              _ptr(bbox), _stream())
+    _check(rc, "sn_voxel_bbox")
+    return bbox
+
+
+def voxel_desc(bbox: torch.Tensor, n_xyz: Sequence[int], regular: bool = True, from_bounds: bool = False):
+    B = bbox.shape[0]
+    nx, ny, nz = (int(v) for v in n_xyz)
+    desc = torch.empty((B, desc_len(nx, ny, nz)), dtype=torch.float64, device=bbox.device)
+    if from_bounds:
+        rc = load().sn_voxel_desc_from_bounds(_ptr(bbox, torch.float64, "bounds"), B, nx, ny, nz, _ptr(desc),
+                                              _stream())
+    else:
+        rc = load().sn_voxel_desc(_ptr(bbox, torch.float64, "bbox"), B, nx, ny, nz, int(regular), _ptr(desc),
+                                  _stream())
+    _check(rc, "sn_voxel_desc")
+    return desc
+
+
+def voxel_scatter(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[float] = (), want_towers: bool = False,
+                  counts=None, towers=None, dropped=None):
+    B = offsets.numel() - 1
+    nx, ny, nz = (int(v) for v in n_xyz)
+    dev = pts.device
+    if counts is None:
+        counts = torch.empty((B, nz, nx, ny), dtype=torch.int32, device=dev)
+    if want_towers and towers is None:
+        towers = torch.empty((B, nz, nx, ny), dtype=torch.int32, device=dev)
+    if dropped is None:
+        dropped = torch.empty((B,), dtype=torch.int32, device=dev)
+    keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
+    rc = load().sn_voxel_scatter(_ptr(pts, torch.float64, "pts"), _ptr(labels, torch.float64, "labels"),
+                                 _ptr(offsets, torch.int64, "offsets"), B, _ptr(desc, torch.float64, "desc"),
+                                 nx, ny, nz, _ptr(counts, torch.int32, "counts"),
+                                 _ptr(towers, torch.int32, "towers") if want_towers else None,
+                                 ctypes.cast(keep, c_void_p), len(keep_labels), _ptr(dropped), _stream())
+    _check(rc, "sn_voxel_scatter")
+    return counts, (towers if want_towers else None), dropped
+
+
+def voxel_finalize(counts, towers, want_density=False, want_gt=False, want_occ=True, want_gt_occ=False):
+    B, nz, nx, ny = counts.shape
+    dev = counts.device
+    shape = (B, 1, nz, nx, ny)
+    colstats = torch.empty((B, 2, ny), dtype=torch.int32, device=dev) if (want_density or want_occ) else None
+    density = torch.empty(shape, dtype=torch.float64, device=dev) if want_density else None
+    gt = torch.empty(shape, dtype=torch.float64, device=dev) if want_gt else None
+    occ = torch.empty(shape, dtype=torch.float32, device=dev) if want_occ else None
+    gt_occ = torch.empty(shape, dtype=torch.float32, device=dev) if want_gt_occ else None
+    rc = load().sn_voxel_finalize(_ptr(counts, torch.int32, "counts"), _ptr(towers, torch.int32, "towers"), B, nx, ny,
+                                  nz, _ptr(colstats), _ptr(density), _ptr(gt), _ptr(occ), _ptr(gt_occ), _stream())
+    _check(rc, "sn_voxel_finalize")
+    return density, gt, occ, gt_occ

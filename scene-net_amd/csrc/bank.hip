@@ -1,0 +1,120 @@
+// K2 -- GENEO bank builder: the parameterised geometric kernels (cylinder, cone/arrow,
+// negative sphere) are built on the fly from their few scalars, one workgroup per GENEO,
+// values staged in LDS for the zero-sum / neg-factor mean subtraction.
+//
+// Follows (closed form of) cylinderv2.compute_kernel  core/models/geneos/cylinder.py:152-176,
+//                           arrow.compute_kernel       core/models/geneos/arrow.py:214-252,
+//                           negSpherev2.compute_kernel core/models/geneos/neg_sphere.py:166-199,
+// including the reference's flat-order re-view ("scramble") for non-square / non-cubic sizes.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kEps = 1e-8f;        // default `epsilon` of the v2 gaussians
+constexpr float kPi = 3.14159274f;   // torch.pi rounded to fp32 by the fp32 multiply
+
+// sig * exp(r^4 * (-1 / (2 (rad + eps)^2)))
+__device__ __forceinline__ float geneo_gauss(float r2, float rad, float sig) {
+    float re = rad + kEps;
+    float c = -1.0f / (2.0f * (re * re));
+    return sig * expf((r2 * r2) * c);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __restrict__ params,
+                                                              const int32_t* __restrict__ kinds, int kz, int kx,
+                                                              int ky, float* __restrict__ bank,
+                                                              int32_t* __restrict__ status) {
+    extern __shared__ float lds[];
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nfloor = kx * ky;
+    const int vol = kz * nfloor;
+    float* vals = lds;          // [vol]
+    float* seg_sum = lds + vol; // [kz] (cy / cone) or [1] (neg)
+
+    const float* p = params + (size_t)g * SN_NPARAM;
+    const int kind = kinds[g];
+    const float radius = p[SN_P_RADIUS];
+    const float sigma = p[SN_P_SIGMA];
+    const float cx = (kx - 1) * 0.5f, cy = (ky - 1) * 0.5f, cz = (kz - 1) * 0.5f;
+
+    int hc = 0;
+    float cone_radius = 0.f, tan_inc = 0.f, neg = 0.f;
+    if (kind == SN_GENEO_CONE) {
+        hc = (int)p[SN_P_APEX];  // truncation, arrow.py:235
+        int bad = (hc < 0 || hc > kz);
+        hc = min(max(hc, 0), kz);
+        if (status && tid == 0) status[g] = bad;
+        cone_radius = p[SN_P_CONE_RADIUS];
+        float inc = fminf(fmaxf(p[SN_P_CONE_INC], 0.0f), 0.499f);  // arrow.py:244
+        tan_inc = tanf(inc * kPi);
+    } else {
+        if (status && tid == 0) status[g] = 0;
+        if (kind == SN_GENEO_NEG) neg = p[SN_P_NEG_FACTOR];
+    }
+
+    for (int idx = tid; idx < vol; idx += kThreads) {
+        float v;
+        if (kind == SN_GENEO_NEG) {
+            // output element idx of the row-major [kz,kx,ky] view takes flat-column row idx, whose
+            // index triple is (k_z, i_x, j_y) = (idx % kz, (idx / kz) % kx, idx / (kz*kx))
+            float dz = (float)(idx % kz) - cz;
+            float dx = (float)((idx / kz) % kx) - cx;
+            float dy = (float)(idx / (kz * kx)) - cy;
+            v = (-neg) * geneo_gauss(dx * dx + dy * dy + dz * dz, radius, sigma);
+        } else {
+            int z = idx / nfloor, n = idx - z * nfloor;
+            // element n of the row-major [kx,ky] view takes flat-column row n = (i_x, j_y) = (n % kx, n / kx)
+            float dx = (float)(n % kx) - cx;
+            float dy = (float)(n / kx) - cy;
+            float rad = radius;
+            if (kind == SN_GENEO_CONE && z < kz - hc) rad = cone_radius * (float)z * tan_inc;
+            v = geneo_gauss(dx * dx + dy * dy, rad, sigma);
+        }
+        vals[idx] = v;
+    }
+    __syncthreads();
+
+    const int nseg = (kind == SN_GENEO_NEG) ? 1 : kz;
+    const int seg_len = (kind == SN_GENEO_NEG) ? vol : nfloor;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int s = wave; s < nseg; s += kThreads / 64) {
+        float acc = 0.f;
+        for (int i = lane; i < seg_len; i += 64) acc += vals[s * seg_len + i];
+        acc = wave_sum(acc);
+        if (lane == 0) seg_sum[s] = acc;
+    }
+    __syncthreads();
+
+    float* out = bank + (size_t)g * vol;
+    for (int idx = tid; idx < vol; idx += kThreads) {
+        float mean;
+        if (kind == SN_GENEO_NEG)
+            mean = (seg_sum[0] + neg) / (float)vol;  // sum_negfactor, neg_sphere.py:181-182
+        else
+            mean = seg_sum[idx / nfloor] / (float)nfloor;  // sum_zero, cylinder.py:81-82
+        out[idx] = vals[idx] - mean;
+    }
+}
+
+}  // namespace
+
+extern "C" int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                             int32_t* status, sn_stream_t stream) {
+    if (!params || !kinds || !bank) return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank: null pointer");
+    if (G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank: non-positive extent (G=%d k=%d,%d,%d)", G, kz, kx, ky);
+    const long vol = (long)kz * kx * ky;
+    if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank: kernel volume %ld > 12000", vol);
+    size_t lds = (size_t)(vol + kz + 1) * sizeof(float);
+    hipLaunchKernelGGL(geneo_bank_kernel, dim3(G), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz, kx,
+                       ky, bank, status);
+    return sn::check_launch("sn_geneo_bank");
+}

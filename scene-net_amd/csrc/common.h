@@ -1,0 +1,28 @@
+// Shared host-side helpers of the C ABI (error text, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "scenenet_hip.h"
+
+namespace sn {
+
+char* error_buffer();  // thread-local, 512 bytes (defined in cabi.hip)
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SN_OK;
+}
+
+inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace sn

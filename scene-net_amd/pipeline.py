@@ -1,0 +1,67 @@
+"""The fused, HBM-resident hot path: ragged point batch -> occupancy grid -> GENEO bank conv -> head.
+
+One process per GPU; voxel tiles are independent, so a job shards its tiles across ranks in
+contiguous chunks with no data-path collective.  The only collectives are the
+barrier / max-over-ranks used to time a job (bench.py).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip
+from .scene_net import SceneNet
+from .voxelization import PointBatch, VoxelGrids, voxelize_batch
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous chunk [lo, hi) of `n_items` tiles owned by `rank`; sizes differ by at most one."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def job_time_max(local_seconds: float, device=None) -> float:
+    """max over ranks of a per-rank wall time (all-reduce MAX on the default process group; identity
+    when torch.distributed is not initialised)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(local_seconds)
+    t = torch.tensor([local_seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_sum(value: float, device=None) -> float:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+class ScenePipeline:
+    """model(ToFullDense(Voxelization(points))) for a whole batch, without leaving HBM.
+
+    Equivalent reference call chain: TS40K.__getitem__ -> Compose([Voxelization, ToTensor, ToFullDense])
+    (core/datasets/ts40k.py:212-213, scripts/main.py:138-140) -> collate -> SceneNet.forward
+    (core/models/SCENE_Net.py:322-339).
+    """
+
+    def __init__(self, model: SceneNet, voxelgrid_dims: Sequence[int] = (64, 64, 64),
+                 keep_labels: Optional[Sequence[float]] = None):
+        self.model = model
+        self.voxelgrid_dims = tuple(int(v) for v in voxelgrid_dims)
+        self.keep_labels = keep_labels
+
+    def voxelize(self, batch: PointBatch, want_gt: bool = False) -> VoxelGrids:
+        return voxelize_batch(batch, self.voxelgrid_dims, self.keep_labels, want_occ=True, want_gt_occ=want_gt)
+
+    def __call__(self, batch: PointBatch, want_gt: bool = False):
+        grids = self.voxelize(batch, want_gt)
+        out = self.model(grids.occ)
+        return (out, grids) if want_gt else out

@@ -1,0 +1,178 @@
+"""Host-side mirror of core/models/SCENE_Net.py: `GENEO_Layer` (:56-113) and `SceneNet` (:229-339).
+
+Same constructor signatures, attribute names, state-dict keys, accessors, RNG draw order at
+construction and forward side effects as the reference, so it drops into
+core/lit_modules/lit_model_wrappers.py:155 unchanged.  The forward itself is two HIP calls:
+sn_geneo_bank (K2) and sn_conv_bank (K3, conv + convex head fused).  No CPU path.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Mapping, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _hip
+from .geneos import CLASS_OF_KEY, GENEO_kernel_torch, pack_params
+
+
+class GENEO_Layer(nn.Module):
+    """SCENE_Net.py:56-113."""
+
+    def __init__(self, geneo_class: GENEO_kernel_torch, kernel_size: tuple = None, smart=False):
+        super().__init__()
+        self.geneo_class = geneo_class
+        self.init_from_config(smart)
+        if kernel_size is not None:
+            self.kernel_size = kernel_size
+
+    def init_from_config(self, smart=False):
+        config = self.geneo_class.geneo_smart_config() if smart else self.geneo_class.geneo_random_config()
+        self.name = config["name"]
+        self.kernel_size = config["kernel_size"]
+        self.plot = config["plot"]
+        params = {}
+        for param in config["geneo_params"]:
+            t_param = torch.as_tensor(config["geneo_params"][param]).clone().detach().to(torch.float)
+            params[param] = nn.Parameter(t_param, requires_grad=param not in config["non_trainable"])
+        self.geneo_params = nn.ParameterDict(params)  # plain dict -> keys sorted, like the reference
+
+    def init_from_kwargs(self, kernel_size, kwargs):
+        self.kernel_size = kernel_size
+        self.name = "GENEO"
+        self.plot = False
+        params = {}
+        for param in self.geneo_class.mandatory_parameters():
+            params[param] = nn.Parameter(torch.tensor(kwargs[param], dtype=torch.float))
+        self.geneo_params = nn.ParameterDict(params)
+
+    def compute_kernel(self) -> torch.Tensor:
+        """[1, kz, kx, ky] float64 (SCENE_Net.py:103-106), built on the HIP device."""
+        geneo = self.geneo_class(self.name, self.kernel_size, plot=self.plot, **self.geneo_params)
+        kernel = geneo.kernel.to(dtype=torch.double)
+        return kernel.view(1, *kernel.shape)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """conv3d(x, kernel, padding='same') -> [B,1,Z,X,Y] (SCENE_Net.py:108-113; the reference's own
+        version reads an undefined self.device)."""
+        geneo = self.geneo_class(self.name, self.kernel_size, plot=self.plot, **self.geneo_params)
+        return geneo.convolution(x)
+
+
+class SceneNet(nn.Module):
+    """SCENE_Net.py:229-339."""
+
+    def __init__(self, geneo_num=None, kernel_size=None, plot=False):
+        super().__init__()
+        self.sizes = {"cy": 1, "cone": 1, "neg": 1} if geneo_num is None else geneo_num
+        if kernel_size is not None:
+            self.kernel_size = kernel_size
+        self.geneos: Mapping[str, GENEO_Layer] = nn.ModuleDict()
+        for key in self.sizes:
+            if key in CLASS_OF_KEY:
+                for i in range(self.sizes[key]):
+                    self.geneos[f"{key}_{i}"] = GENEO_Layer(CLASS_OF_KEY[key], kernel_size=kernel_size)
+
+        # --- convex coefficients (SCENE_Net.py:274-293), same RNG draws
+        num_lambdas = sum(self.sizes.values())
+        lambda_init_max = 1 / num_lambdas
+        lambda_init_min = -2 / num_lambdas
+        lambdas = (lambda_init_max - lambda_init_min) * torch.rand(num_lambdas, dtype=torch.float) + lambda_init_min
+        lambdas = [nn.Parameter(lamb) for lamb in lambdas]
+        self.lambda_names = [f"lambda_{key}_{i}" for key, val in self.sizes.items() for i in range(val)]
+        self.last_lambda = self.lambda_names[torch.randint(0, num_lambdas, (1,))[0]]
+        if plot:
+            print(f"last cvx_coeff: {self.last_lambda}")
+        d = dict(zip(self.lambda_names, lambdas))  # last cvx_coeff is 1 - sum(others)
+        d[self.last_lambda] = nn.Parameter(1 - sum(d.values()) + d[self.last_lambda], requires_grad=False)
+        self.lambdas_dict = nn.ParameterDict(d)
+        self._pack_cache = None
+        self._warned_grad = False
+        if plot:
+            print(f"Total Number of train params = {self.get_num_total_params()}")
+
+    # ------------------------------------------------------------------ accessors (SCENE_Net.py:299-319)
+    def get_cvx_coefficients(self):
+        return self.lambdas_dict
+
+    def get_num_total_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def get_model_parameters(self, detach=False):
+        if detach:
+            return {name: param.detach().clone() for name, param in self.named_parameters()}
+        return {name: param for name, param in self.named_parameters()}
+
+    def get_geneo_params(self):
+        return nn.ParameterDict(dict([(name.replace(".", "_"), p) for name, p in self.named_parameters()
+                                      if "lambda" not in name]))
+
+    def get_model_parameters_in_dict(self):
+        ddd = {}
+        for key, val in self.named_parameters():
+            key_split = key.split(".")
+            parameter_name = f"{key_split[-3]}.{key_split[-1]}" if "geneo" in key else key_split[-1]
+            ddd[parameter_name] = val.data.item()
+        return ddd
+
+    # ------------------------------------------------------------------ host logic
+    def kernel_size_of_bank(self) -> Tuple[int, int, int]:
+        sizes = {tuple(int(k) for k in layer.kernel_size) for layer in self.geneos.values()}
+        if len(sizes) != 1:
+            raise RuntimeError(f"GENEO kernels of different sizes cannot be stacked: {sizes}")  # torch.stack fails
+        return next(iter(sizes))
+
+    def packed_params(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """([G, SN_NPARAM] f32, [G] i32) on `device`; re-packed only when a parameter changed."""
+        key = (str(device),) + tuple((id(p), p._version) for l in self.geneos.values() for p in l.geneo_params.values())
+        if self._pack_cache is not None and self._pack_cache[0] == key:
+            return self._pack_cache[1], self._pack_cache[2]
+        rows, kinds = [], []
+        for layer in self.geneos.values():
+            kind = layer.geneo_class.KIND
+            for m in layer.geneo_class.mandatory_parameters():
+                if m not in layer.geneo_params:
+                    raise KeyError(f"GENEO {layer.name}: missing mandatory parameter {m}")
+            rows.append(pack_params(kind, layer.geneo_params, device))
+            kinds.append(kind)
+            if kind == _hip.SN_GENEO_CONE:
+                hc = int(layer.geneo_params["apex"].detach().to(torch.int).item())
+                if hc < 0 or hc > int(layer.kernel_size[0]):
+                    raise RuntimeError(f"arrow: int(apex)={hc} outside [0, {layer.kernel_size[0]}]")
+        params = torch.stack(rows).contiguous()
+        kinds_t = torch.tensor(kinds, dtype=torch.int32, device=device)
+        self._pack_cache = (key, params, kinds_t)
+        return params, kinds_t
+
+    def effective_lambdas(self, device) -> torch.Tensor:
+        """[G] f32 in GENEO order; the `last_lambda` entry is 1 - sum(lambdas_dict.values()) + last
+        (SCENE_Net.py:331), summed in ParameterDict order like the reference.  Also performs the
+        reference's side effect of re-creating lambdas_dict[last_lambda] (SCENE_Net.py:333)."""
+        last = 1 - sum(self.lambdas_dict.values()) + self.lambdas_dict[self.last_lambda]
+        self.lambdas_dict[self.last_lambda] = nn.Parameter(last.detach(), requires_grad=False)
+        vals = [self.lambdas_dict[f"lambda_{g}"].detach() for g in self.geneos]
+        return torch.stack(vals).to(device=device, dtype=torch.float32).contiguous()
+
+    def compute_bank(self, device=None) -> torch.Tensor:
+        """[G, kz, kx, ky] f32 on the HIP device (the stack at SCENE_Net.py:324, before the fp64 cast)."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        params, kinds = self.packed_params(device)
+        return _hip.geneo_bank(params, kinds, self.kernel_size_of_bank())
+
+    def forward(self, x: torch.Tensor, return_bank_activations: bool = False):
+        """x [B,1,Z,X,Y] on a HIP device -> relu(tanh(sum_i lambda_i conv3d(x, K_i))) [B,1,Z,X,Y], same dtype.
+        With return_bank_activations=True also returns conv [B,G,Z,X,Y] (SCENE_Net.py:325)."""
+        if not x.is_cuda:
+            raise _hip.HipLibraryError("SceneNet.forward runs on the HIP device only (no CPU fallback): move x to cuda")
+        if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
+            warnings.warn("scene-net_amd: forward path only -- the HIP conv has no backward yet (SURVEY 8f-2); "
+                          "the output does not require grad")
+            self._warned_grad = True
+        with torch.no_grad():
+            bank = self.compute_bank(x.device)
+            lam = self.effective_lambdas(x.device)
+            out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
+            act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
+                                      out_dtype=out_dtype)
+        return (out, act) if return_bank_activations else out

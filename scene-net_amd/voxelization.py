@@ -1,0 +1,148 @@
+"""Host-side mirror of the voxelisation step: utils/voxelization.py:164-204 (`hist_on_voxel`),
+:244-300 (`reg_on_voxel`), :304-323 (`prob_to_label`) over eda.voxelize_ply
+(utils/pcd_processing.py:341-372) / pyntcloud VoxelGrid.
+
+`hist_on_voxel` / `reg_on_voxel` keep the reference's numpy-in / numpy-out signatures (host
+buffers: PCIe-inclusive).  `voxelize_batch` is the HBM-resident form the fused pipeline and the
+bench use: a ragged batch of tiles -> device grids in one pass of the HIP kernels
+(csrc/voxel.hip).  No CPU path: everything below calls the C ABI.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _hip
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+@dataclass
+class PointBatch:
+    """Ragged batch of tiles resident in HBM: pts [total,3] f64, labels [total] f64 | None, offsets [B+1] i64."""
+    pts: torch.Tensor
+    labels: Optional[torch.Tensor]
+    offsets: torch.Tensor
+    sizes: Tuple[int, ...]
+
+    @property
+    def batch(self) -> int:
+        return len(self.sizes)
+
+    @property
+    def total_points(self) -> int:
+        return int(sum(self.sizes))
+
+    @staticmethod
+    def from_tiles(tiles: Sequence[ArrayLike], labels: Optional[Sequence[ArrayLike]] = None,
+                   device=None) -> "PointBatch":
+        """Concatenates per-tile [N_b,3] arrays (numpy or torch, any device) into one CSR batch on the HIP device."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise _hip.HipLibraryError("PointBatch lives in HBM: device must be a HIP device")
+        sizes = tuple(int(t.shape[0]) for t in tiles)
+        for t in tiles:
+            if t.ndim != 2 or t.shape[1] != 3:
+                raise ValueError(f"each tile must be [N,3] (got {tuple(t.shape)})")
+        if any(n == 0 for n in sizes):
+            # numpy's min() of an empty array raises in pyntcloud's VoxelGrid.compute
+            raise ValueError("zero-size array to reduction operation minimum which has no identity (empty tile)")
+        as_t = lambda a: (torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)) if isinstance(a, np.ndarray)
+                          else a.to(torch.float64))  # noqa: E731
+        pts = torch.cat([as_t(t) for t in tiles]).to(device).contiguous()
+        lab = None
+        if labels is not None:
+            lab = torch.cat([as_t(l).reshape(-1) for l in labels]).to(device).contiguous()
+            if lab.numel() != pts.shape[0]:
+                raise ValueError("labels and points disagree in length")
+        offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=device)
+        return PointBatch(pts, lab, offsets, sizes)
+
+
+@dataclass
+class VoxelGrids:
+    counts: torch.Tensor                 # [B,nz,nx,ny] i32
+    towers: Optional[torch.Tensor]       # [B,nz,nx,ny] i32
+    density: Optional[torch.Tensor]      # [B,1,nz,nx,ny] f64  hist_on_voxel
+    gt: Optional[torch.Tensor]           # [B,1,nz,nx,ny] f64  reg_on_voxel
+    occ: Optional[torch.Tensor]          # [B,1,nz,nx,ny] f32  ToFullDense(density)
+    gt_occ: Optional[torch.Tensor]       # [B,1,nz,nx,ny] f32  ToFullDense(gt)
+    desc: torch.Tensor                   # [B, 6+nx+ny+nz+3] f64: lo, hi, edges
+    dropped: torch.Tensor                # [B] i32
+
+
+def _labels_list(tower_label) -> List[float]:
+    return [float(v) for v in np.array(tower_label).reshape(-1)]
+
+
+def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 64),
+                   keep_labels: Optional[Sequence[float]] = None, want_density: bool = False,
+                   want_gt: bool = False, want_occ: bool = True, want_gt_occ: bool = False,
+                   bounds: Optional[torch.Tensor] = None) -> VoxelGrids:
+    """n_x/n_y/n_z mode of voxelize_ply for a whole batch.  `voxelgrid_dims` is (x, y, z) like the
+    reference (pcd_processing.py:362-363); grids come back [.., nz, nx, ny] (voxelization.py:193)."""
+    nx, ny, nz = (int(v) for v in voxelgrid_dims)
+    want_t = (want_gt or want_gt_occ)
+    if want_t and (batch.labels is None or keep_labels is None):
+        raise ValueError("ground-truth grids need labels and keep_labels")
+    if bounds is None:
+        bbox = _hip.voxel_bbox(batch.pts, batch.offsets)
+        desc = _hip.voxel_desc(bbox, (nx, ny, nz), regular=True)
+    else:
+        desc = _hip.voxel_desc(bounds, (nx, ny, nz), from_bounds=True)
+    counts, towers, dropped = _hip.voxel_scatter(batch.pts, batch.labels if want_t else None, batch.offsets, desc,
+                                                 (nx, ny, nz), _labels_list(keep_labels) if want_t else (),
+                                                 want_towers=want_t)
+    density, gt, occ, gt_occ = _hip.voxel_finalize(counts, towers, want_density, want_gt, want_occ, want_gt_occ)
+    return VoxelGrids(counts, towers, density, gt, occ, gt_occ, desc, dropped)
+
+
+def _size_mode_bounds(bbox: np.ndarray, sizes: Sequence[float]):
+    """pyntcloud VoxelGrid.compute with size_x/size_y/size_z (pcd_processing.py:365-367): cube the box,
+    then extend each axis by ((range // size) + 1) * size - range (range = the ORIGINAL ptp) and set
+    n = int((max - min) / size).  Host fp64 arithmetic on the 6 bbox numbers of one tile."""
+    xyzmin, xyzmax = bbox[:3].copy(), bbox[3:].copy()
+    xyz_range = xyzmax - xyzmin
+    margin = max(xyz_range) - xyz_range
+    xyzmin = xyzmin - margin / 2
+    xyzmax = xyzmax + margin / 2
+    n = [1, 1, 1]
+    for a, size in enumerate(sizes):
+        m = (((xyz_range[a] // size) + 1) * size) - xyz_range[a]
+        xyzmin[a] -= m / 2
+        xyzmax[a] += m / 2
+        n[a] = int((xyzmax[a] - xyzmin[a]) / size)
+    return np.concatenate([xyzmin, xyzmax]), tuple(n)
+
+
+def _voxelize_single(xyz: ArrayLike, labels, tower_label, voxelgrid_dims, voxel_dims, **wants) -> VoxelGrids:
+    batch = PointBatch.from_tiles([xyz], None if labels is None else [labels])
+    if voxel_dims is None:
+        return voxelize_batch(batch, voxelgrid_dims, tower_label, **wants)
+    # voxel_dims overrides voxelgrid_dims; grid extents are data dependent -> one host round trip of the bbox
+    bbox = _hip.voxel_bbox(batch.pts, batch.offsets).cpu().numpy()[0]
+    bounds, n = _size_mode_bounds(bbox, voxel_dims)
+    b = torch.from_numpy(bounds[None]).to(batch.pts.device)
+    return voxelize_batch(batch, n, tower_label, bounds=b, **wants)
+
+
+def hist_on_voxel(xyz, voxelgrid_dims=(64, 64, 64), voxel_dims=None) -> np.ndarray:
+    """voxelization.py:164-204: per-voxel point count, min-max normalised per y column -> [nz,nx,ny] f64."""
+    g = _voxelize_single(xyz, None, None, voxelgrid_dims, voxel_dims, want_density=True, want_occ=False)
+    return g.density[0, 0].cpu().numpy()
+
+
+def reg_on_voxel(xyz, labels, tower_label, voxelgrid_dims=(64, 64, 64), voxel_dims=None) -> np.ndarray:
+    """voxelization.py:244-300: fraction of `tower_label` points per occupied voxel -> [nz,nx,ny] f64."""
+    g = _voxelize_single(xyz, labels, tower_label, voxelgrid_dims, voxel_dims, want_gt=True, want_occ=False)
+    return g.gt[0, 0].cpu().numpy()
+
+
+def prob_to_label(voxelgrid, tau: float):
+    """voxelization.py:304-323."""
+    if isinstance(voxelgrid, torch.Tensor):
+        return (voxelgrid >= tau).to(voxelgrid.dtype)
+    return (voxelgrid >= tau).astype(voxelgrid.dtype)

@@ -1,0 +1,236 @@
+"""
+Generates tests/golden/geneo_*.npz by IMPORTING the reference (dlavado/scene-net at
+/root/reference) in the build container.  The reference never travels: only the
+arrays written here are committed.  Run from the repo root:
+
+    python tests/golden/make_golden.py
+
+Third-party modules the reference imports for plotting / IO only (pyntcloud,
+open3d, laspy, ...) are absent from the image and are replaced by MagicMock
+before import; the compute path (torch only) is the reference's
+own code, executed unmodified.
+"""
+import importlib
+import os
+import sys
+import warnings
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("SCENENET_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+for name in ["pyntcloud", "open3d", "laspy", "webcolors", "sympytorch", "IPython", "IPython.display", "seaborn",
+             "torchvision", "torchvision.transforms", "pytorch_lightning", "pytorch_lightning.callbacks", "wandb",
+             "torchmetrics", "torchviz", "torchsummary"]:
+    try:
+        importlib.import_module(name)
+    except Exception:
+        sys.modules[name] = MagicMock()
+
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+from core.models.geneos import cylinder, arrow, neg_sphere  # noqa: E402
+from core.models.SCENE_Net import SceneNet  # noqa: E402
+
+T = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+
+KERNEL_SIZES = [(9, 9, 9), (9, 7, 7), (9, 5, 5), (6, 5, 5), (9, 6, 6), (5, 7, 3), (3, 3, 3), (4, 6, 5)]
+
+CY_PARAMS = [dict(radius=2.5, sigma=1.8), dict(radius=0.998896, sigma=1.199054), dict(radius=4.0, sigma=0.5),
+             dict(radius=0.5, sigma=2.0)]
+CONE_PARAMS = [dict(radius=1.5, sigma=0.955910, apex=0.0, cone_radius=4.000988, cone_inc=0.565547),  # trained ckpt
+               dict(radius=2.0, sigma=1.4, apex=4.0, cone_radius=3.0, cone_inc=0.2),
+               dict(radius=3.5, sigma=1.0, apex=2.7, cone_radius=1.5, cone_inc=0.45),
+               dict(radius=1.0, sigma=2.0, apex=3.0, cone_radius=2.0, cone_inc=0.1),  # smart config, arrow.py:143-151
+               dict(radius=2.0, sigma=1.2, apex=1.0, cone_radius=2.5, cone_inc=-0.3)]  # clamp to 0
+NEG_PARAMS = [dict(radius=3.000918, sigma=0.605097, neg_factor=0.127053),  # trained ckpt
+              dict(radius=2.0, sigma=0.9, neg_factor=0.2), dict(radius=5.0, sigma=0.5, neg_factor=0.9)]
+
+
+def dump_kernels():
+    out = {}
+    meta = []
+    for ks in KERNEL_SIZES:
+        for i, p in enumerate(CY_PARAMS):
+            k = cylinder.cylinderv2("cy", ks, **{n: T(v) for n, v in p.items()}).kernel
+            key = f"cy|{ks}|{i}"
+            out[key] = k.detach().cpu().numpy()
+            meta.append((key, "cy", ks, p))
+        for i, p in enumerate(CONE_PARAMS):
+            if int(p["apex"]) > ks[0]:
+                continue
+            k = arrow.arrow("cone", ks, **{n: T(v) for n, v in p.items()}).kernel
+            key = f"cone|{ks}|{i}"
+            out[key] = k.detach().cpu().numpy()
+            meta.append((key, "cone", ks, p))
+        for i, p in enumerate(NEG_PARAMS):
+            k = neg_sphere.negSpherev2("neg", ks, **{n: T(v) for n, v in p.items()}).kernel
+            key = f"neg|{ks}|{i}"
+            out[key] = k.detach().cpu().numpy()
+            meta.append((key, "neg", ks, p))
+    np.savez_compressed(os.path.join(OUT, "geneo_kernels.npz"), **out)
+    import json
+    with open(os.path.join(OUT, "geneo_kernels_meta.json"), "w") as f:
+        json.dump([dict(key=k, kind=kind, kernel_size=list(ks), params=p) for k, kind, ks, p in meta], f, indent=0)
+    print(f"geneo_kernels.npz: {len(out)} kernels")
+
+
+def set_model(model, geneo_params, lambdas, last):
+    with torch.no_grad():
+        for gname, p in geneo_params.items():
+            for pname, v in p.items():
+                model.geneos[gname].geneo_params[pname].fill_(v)
+        for lname, v in lambdas.items():
+            model.lambdas_dict[lname].fill_(v)
+    model.last_lambda = last
+
+
+def forward_case(tag, geneo_num, ks, grid, batch, geneo_params, lambdas, last, seed, density):
+    torch.manual_seed(0)
+    model = SceneNet(geneo_num, ks)
+    set_model(model, geneo_params, lambdas, last)
+    rng = np.random.default_rng(seed)
+    x = (rng.random((batch, 1) + tuple(grid)) < density).astype(np.float64)
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        kernels = torch.stack([model.geneos[g].compute_kernel() for g in model.geneos])
+        conv = torch.nn.functional.conv3d(xt, kernels, padding="same")
+        out = model(xt)
+    names = list(model.geneos.keys())
+    return {
+        f"{tag}/x": x.astype(np.uint8), f"{tag}/bank": kernels.numpy(), f"{tag}/conv": conv.numpy(),
+        f"{tag}/out": out.numpy(), f"{tag}/names": np.array(names),
+        f"{tag}/lambdas": np.array([lambdas[f"lambda_{n}"] for n in names], dtype=np.float32),
+        f"{tag}/last": np.array(names.index(last.replace("lambda_", ""))),
+        f"{tag}/kernel_size": np.array(ks),
+        f"{tag}/lambda_last_after": np.array(model.lambdas_dict[last].item(), dtype=np.float32),
+    }, {tag: dict(geneo_params=geneo_params, names=names)}
+
+
+def dump_forward():
+    out, meta = {}, {}
+    # (1) the trained checkpoint's 13 scalars, kernel (9,5,5), 3 GENEOs
+    ckpt_params = {"cy_0": dict(radius=0.998896, sigma=1.199054),
+                   "cone_0": dict(apex=0.0, cone_inc=0.565547, cone_radius=4.000988, radius=1.5, sigma=0.955910),
+                   "neg_0": dict(neg_factor=0.127053, radius=3.000918, sigma=0.605097)}
+    ckpt_lam = {"lambda_cy_0": 0.024178, "lambda_cone_0": 0.608911, "lambda_neg_0": 0.366911}
+    a, m = forward_case("ckpt955", {"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5), (24, 20, 16), 2, ckpt_params, ckpt_lam,
+                        "lambda_neg_0", seed=11, density=0.08)
+    out.update(a); meta.update(m)
+    # (2) C1-shaped bank (cy 2, cone 1, neg 1), cubic 9^3, explicit params
+    rng = np.random.default_rng(7)
+    def rp(kind):
+        if kind == "cy":
+            return dict(radius=float(rng.uniform(0.5, 4)), sigma=float(rng.uniform(0.5, 2)))
+        if kind == "cone":
+            return dict(radius=float(rng.uniform(0.5, 4)), sigma=float(rng.uniform(0.5, 2)),
+                        apex=float(rng.integers(4, 8)), cone_radius=float(rng.uniform(0.5, 4)),
+                        cone_inc=float(rng.uniform(0.05, 0.45)))
+        return dict(radius=float(rng.uniform(0.5, 4)), sigma=float(rng.uniform(0.5, 2)),
+                    neg_factor=float(rng.uniform(0.1, 0.9)))
+    def make(geneo_num):
+        gp, names = {}, []
+        for kind, n in geneo_num.items():
+            for i in range(n):
+                gp[f"{kind}_{i}"] = rp(kind); names.append(f"{kind}_{i}")
+        G = len(names)
+        lam = {f"lambda_{n}": float(rng.uniform(-2 / G, 1 / G)) for n in names}
+        return gp, lam
+    gp, lam = make({"cy": 2, "cone": 1, "neg": 1})
+    a, m = forward_case("c1_999", {"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9), (20, 20, 20), 2, gp, lam,
+                        "lambda_cone_0", seed=12, density=0.1)
+    out.update(a); meta.update(m)
+    # (3) full 16-kernel bank on a small grid
+    gp, lam = make({"cy": 6, "cone": 5, "neg": 5})
+    a, m = forward_case("g16_999", {"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9), (16, 16, 16), 1, gp, lam,
+                        "lambda_cy_3", seed=13, density=0.15)
+    out.update(a); meta.update(m)
+    # (4) even kernel dims -> asymmetric 'same' padding; non-square footprint scramble
+    gp, lam = make({"cy": 1, "cone": 2, "neg": 2})
+    a, m = forward_case("even_656", {"cy": 1, "cone": 2, "neg": 2}, (6, 5, 6), (12, 14, 18), 2,
+                        {k: ({**v, "apex": 2.0} if "apex" in v else v) for k, v in gp.items()}, lam,
+                        "lambda_neg_1", seed=14, density=0.2)
+    out.update(a); meta.update(m)
+    np.savez_compressed(os.path.join(OUT, "geneo_forward.npz"), **out)
+    import json
+    with open(os.path.join(OUT, "geneo_forward_meta.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    print("geneo_forward.npz:", sorted({k.split('/')[0] for k in out}))
+
+
+def dump_module_contract():
+    """State-dict keys / accessor names the drop-in must keep."""
+    torch.manual_seed(3)
+    model = SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9))
+    import json
+    contract = dict(
+        state_dict_keys=list(model.state_dict().keys()),
+        named_parameters=[n for n, _ in model.named_parameters()],
+        requires_grad={n: bool(p.requires_grad) for n, p in model.named_parameters()
+                       if "lambda" not in n},
+        geneo_param_names=list(model.get_geneo_params().keys()),
+        in_dict_keys=list(model.get_model_parameters_in_dict().keys()),
+        cvx_keys=list(model.get_cvx_coefficients().keys()),
+        n_frozen_lambdas=sum(1 for n, p in model.named_parameters() if "lambda" in n and not p.requires_grad),
+        # construction under torch.manual_seed(3): the drop-in makes the same RNG draws in the same order
+        seed=3, seeded_values=model.get_model_parameters_in_dict(), seeded_last_lambda=model.last_lambda,
+        num_total_params=model.get_num_total_params(),
+    )
+    with open(os.path.join(OUT, "module_contract.json"), "w") as f:
+        json.dump(contract, f, indent=1)
+    print("module_contract.json:", len(contract["state_dict_keys"]), "keys")
+
+
+def dump_voxel_normalize():
+    """normalize_xyz (pcd_processing.py:305-321) and ToFullDense (torch_transforms.py:17-40) run on
+    integer count grids -- the two steps of the voxel path that do NOT depend on pyntcloud."""
+    from utils import pcd_processing as eda
+    from core.datasets.torch_transforms import ToFullDense
+    rng = np.random.default_rng(21)
+    out = {}
+    cases = {
+        "sparse": (rng.random((6, 5, 7)) < 0.2) * rng.integers(1, 40, (6, 5, 7)),
+        "dense": rng.integers(0, 9, (4, 4, 4)),
+        "fullcol": np.where(np.arange(5)[None, None, :] == 2, rng.integers(3, 9, (3, 4, 5)),
+                            (rng.random((3, 4, 5)) < 0.5) * rng.integers(1, 5, (3, 4, 5))),  # column y=2 has min > 0
+        "constcol": np.where(np.arange(5)[None, None, :] == 1, 4, rng.integers(0, 3, (3, 4, 5))),  # max == min > 0
+        "empty": np.zeros((3, 3, 3), dtype=np.int64),
+    }
+    dens = ToFullDense(apply=(True, True))
+    for k, c in cases.items():
+        c = c.astype(np.float64)
+        _, norm = eda.normalize_xyz(c.copy())
+        out[f"{k}/counts"] = c
+        out[f"{k}/norm"] = norm
+        v, g = dens((torch.from_numpy(norm), torch.from_numpy(norm * 0.5)))
+        out[f"{k}/dense"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "voxel_normalize.npz"), **out)
+    print("voxel_normalize.npz:", list(cases))
+
+
+def dump_real_tile_subset():
+    """A ~6k-point subset of the reference's data-sample/sample_575.npy (TS40K tile, (N,4) f64 x,y,z,label at
+    UTM scale): the six bbox-defining points, every tower (label 15) point and a random remainder."""
+    a = np.load(os.path.join(REF, "data-sample", "sample_575.npy"))
+    rng = np.random.default_rng(575)
+    idx = set()
+    for c in range(3):
+        idx.add(int(a[:, c].argmin())); idx.add(int(a[:, c].argmax()))
+    idx.update(np.where(a[:, 3] == 15)[0].tolist())
+    idx.update(rng.choice(len(a), 6000 - len(idx), replace=False).tolist())
+    sub = a[np.array(sorted(idx))[:6000]]
+    np.save(os.path.join(OUT, "ts40k_sample575_subset.npy"), sub)
+    print("ts40k_sample575_subset.npy:", sub.shape)
+
+
+if __name__ == "__main__":
+    dump_real_tile_subset()
+    dump_voxel_normalize()
+    dump_kernels()
+    dump_forward()
+    dump_module_contract()

@@ -1,0 +1,172 @@
+"""K3 parity on the MI355X: the MFMA bank convolution + fused head (through the C ABI) against the reference's
+golden forward vectors, against the oracle on seeded inputs, and through size-independent properties at
+BASELINE's full size.  Tolerance (north_star): activations within 1e-4 of the fp64 reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from scene_net_amd import _hip
+from oracle import geneo_oracle as go
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rand_bank(G, ks, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand((G,) + tuple(ks), generator=g) - 0.5).to(dev)
+
+
+@pytest.mark.parametrize("tag", ["ckpt955", "c1_999", "g16_999", "even_656"])
+def test_golden_forward(hip_device, golden_dir, tag):
+    F = np.load(os.path.join(golden_dir, "geneo_forward.npz"))
+    names = [str(n) for n in F[f"{tag}/names"]]
+    bank = torch.from_numpy(F[f"{tag}/bank"][:, 0]).float().to(hip_device).contiguous()
+    lam = go.effective_lambdas(F[f"{tag}/lambdas"], int(F[f"{tag}/last"]), names).to(hip_device)
+    x = torch.from_numpy(F[f"{tag}/x"].astype(np.float64)).to(hip_device)
+    act, out = _hip.conv_bank(x, bank, lam, want_act=True, want_out=True)
+    assert out.dtype == torch.float64 and out.shape == x.shape
+    e_act = (act.cpu() - torch.from_numpy(F[f"{tag}/conv"])).abs().max().item()
+    e_out = (out.cpu() - torch.from_numpy(F[f"{tag}/out"])).abs().max().item()
+    print(tag, "act err", e_act, "out err", e_out)
+    assert e_act < TOL and e_out < TOL
+
+
+@pytest.mark.parametrize("shape,ks,G", [
+    ((2, 1, 16, 16, 16), (9, 9, 9), 16),
+    ((1, 1, 13, 9, 70), (9, 9, 9), 16),      # ragged: not multiples of the tile, y > 64
+    ((3, 1, 8, 10, 33), (9, 5, 5), 3),       # reference default bank
+    ((1, 1, 20, 6, 130), (6, 5, 6), 5),      # even dims: pad left (k-1)//2, right k//2
+    ((2, 1, 5, 4, 3), (3, 3, 3), 1),         # grid smaller than the kernel halo
+    ((1, 1, 9, 9, 9), (1, 1, 1), 2),         # pointwise
+    ((1, 1, 12, 12, 12), (5, 7, 3), 7),
+    ((1, 1, 7, 7, 40), (3, 3, 25), 4),       # widest supported ky
+])
+def test_against_oracle_random_fp32(hip_device, shape, ks, G):
+    torch.manual_seed(hash((shape, ks, G)) % 2**31)
+    x = torch.randn(shape)  # arbitrary (non-binary) input
+    bank = _rand_bank(G, ks, 5, "cpu")
+    lam = (torch.rand(G) - 0.3) / G
+    ref_act = go.conv_bank(x.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    act, out = _hip.conv_bank(x.to(hip_device), bank.to(hip_device).contiguous(), lam.to(hip_device),
+                              want_act=True, want_out=True)
+    scale = max(1.0, ref_act.abs().max().item())
+    assert (act.cpu().double() - ref_act).abs().max().item() < TOL * scale
+    assert (out.cpu().double() - ref_out).abs().max().item() < TOL
+
+
+def test_input_and_output_dtypes(hip_device):
+    torch.manual_seed(1)
+    occ = (torch.rand(2, 1, 16, 12, 20) < 0.1)
+    bank = _rand_bank(16, (9, 9, 9), 2, hip_device).contiguous()
+    lam = torch.full((16,), 1 / 16, device=hip_device)
+    outs = {}
+    for name, x in (("u8", occ.to(torch.uint8)), ("f32", occ.float()), ("f64", occ.double())):
+        act, out = _hip.conv_bank(x.to(hip_device), bank, lam, want_act=True, want_out=True)
+        outs[name] = (act.double().cpu(), out.double().cpu(), out.dtype)
+    assert outs["u8"][2] == torch.float32 and outs["f32"][2] == torch.float32 and outs["f64"][2] == torch.float64
+    for name in ("f32", "f64"):
+        assert torch.equal(outs[name][0].float(), outs["u8"][0].float())  # same fp32 arithmetic inside
+        assert torch.equal(outs[name][1].float(), outs["u8"][1].float())
+    _, o32 = _hip.conv_bank(occ.double().to(hip_device), bank, lam, out_dtype=torch.float32)
+    assert o32.dtype == torch.float32
+
+
+def test_only_act_or_only_out(hip_device):
+    x = (torch.rand(1, 1, 10, 10, 10) < 0.2).float().to(hip_device)
+    bank = _rand_bank(4, (3, 3, 3), 3, hip_device).contiguous()
+    lam = torch.tensor([0.1, 0.2, 0.3, 0.4], device=hip_device)
+    act, none = _hip.conv_bank(x, bank, None, want_act=True, want_out=False)
+    assert none is None and act.shape == (1, 4, 10, 10, 10)
+    none, out = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True)
+    assert none is None
+    ref = torch.relu(torch.tanh((lam.view(1, 4, 1, 1, 1) * act).sum(1, keepdim=True)))
+    assert (out - ref).abs().max().item() < 1e-6
+    with pytest.raises(sna.HipLibraryError):
+        _hip.conv_bank(x, bank, None, want_act=False, want_out=True)  # out needs lambdas
+    with pytest.raises(sna.HipLibraryError):
+        _hip.conv_bank(x, _rand_bank(17, (3, 3, 3), 3, hip_device).contiguous(), None, want_act=True, want_out=False)
+
+
+def test_full_size_c2_tile_against_oracle(hip_device):
+    """One tile at BASELINE C2 size (64^3, 16 kernels of 9^3) against the fp64 oracle."""
+    rng = np.random.default_rng(7)
+    specs = []
+    for kind, n in (("cy", 6), ("cone", 5), ("neg", 5)):
+        for _ in range(n):
+            p = dict(radius=float(rng.uniform(0.5, 4)), sigma=float(rng.uniform(0.5, 2)))
+            if kind == "cone":
+                p.update(apex=float(rng.integers(4, 8)), cone_radius=float(rng.uniform(0.5, 4)),
+                         cone_inc=float(rng.uniform(0.05, 0.45)))
+            if kind == "neg":
+                p.update(neg_factor=float(rng.uniform(0.1, 0.9)))
+            specs.append((kind, p))
+    G = len(specs)
+    lam = rng.uniform(-2 / G, 1 / G, G).astype(np.float32)
+    names = [f"{k}_{i}" for i, (k, _) in enumerate(specs)]
+    x = torch.from_numpy((rng.random((1, 1, 64, 64, 64)) < 0.035).astype(np.float64))
+    ref_out, ref_act = go.scenenet_forward(x, specs, (9, 9, 9), lam, 3, return_bank=True, names=names)
+    bank = go.geneo_bank(specs, (9, 9, 9))[:, 0].float().to(hip_device).contiguous()
+    lam_eff = go.effective_lambdas(lam, 3, names).to(hip_device)
+    act, out = _hip.conv_bank(x.to(hip_device), bank, lam_eff, want_act=True, want_out=True)
+    e_act = (act.cpu() - ref_act).abs().max().item()
+    e_out = (out.cpu() - ref_out).abs().max().item()
+    print("C2 tile: act err", e_act, "out err", e_out, "act max", ref_act.abs().max().item())
+    assert e_act < TOL and e_out < TOL
+
+
+def test_full_size_properties_batch32(hip_device):
+    """BASELINE C2 batch (32 x 64^3, G = 16, 9^3): linearity over disjoint occupancy, batch independence,
+    shift equivariance, output range -- no oracle needed at this size."""
+    torch.manual_seed(3)
+    B = 32
+    bank = _rand_bank(16, (9, 9, 9), 11, hip_device).contiguous() * 0.05
+    lam = ((torch.rand(16) - 0.6) / 4).to(hip_device)
+    occ = torch.rand(B, 1, 64, 64, 64, device=hip_device) < 0.035
+    half = torch.rand(B, 1, 64, 64, 64, device=hip_device) < 0.5
+    x, x1, x2 = occ.to(torch.uint8), (occ & half).to(torch.uint8), (occ & ~half).to(torch.uint8)
+    act, out = _hip.conv_bank(x, bank, lam, want_act=True, want_out=True)
+    a1, _ = _hip.conv_bank(x1, bank, lam, want_act=True, want_out=False)
+    a2, _ = _hip.conv_bank(x2, bank, lam, want_act=True, want_out=False)
+    assert (act - (a1 + a2)).abs().max().item() < 1e-4  # linearity
+    del a1, a2
+    # the head is exactly relu(tanh(sum lambda_i act_i))
+    ref = torch.relu(torch.tanh((lam.view(1, 16, 1, 1, 1) * act).sum(1, keepdim=True)))
+    assert (out - ref).abs().max().item() < 2e-6
+    assert out.min().item() >= 0 and out.max().item() < 1
+    # batch independence: tile 5 alone == tile 5 in the batch, bit for bit
+    a5, o5 = _hip.conv_bank(x[5:6].contiguous(), bank, lam, want_act=True, want_out=True)
+    assert torch.equal(a5, act[5:6]) and torch.equal(o5, out[5:6])
+    # shift equivariance away from the borders: moving the occupancy by (3,-2,5) moves the response
+    xs = torch.zeros_like(x[:1])
+    xs[:, :, 11:51, 8:48, 13:53] = x[:1, :, 8:48, 10:50, 8:48]
+    a_s, _ = _hip.conv_bank(xs, bank, lam, want_act=True, want_out=False)
+    x0 = torch.zeros_like(x[:1])
+    x0[:, :, 8:48, 10:50, 8:48] = x[:1, :, 8:48, 10:50, 8:48]
+    a_0, _ = _hip.conv_bank(x0, bank, lam, want_act=True, want_out=False)
+    assert (a_s[:, :, 7:55, 4:52, 9:57] - a_0[:, :, 4:52, 6:54, 4:52]).abs().max().item() < 1e-5
+    # determinism
+    act2, out2 = _hip.conv_bank(x, bank, lam, want_act=True, want_out=True)
+    assert torch.equal(act, act2) and torch.equal(out, out2)
+
+
+def test_128_cubed_tile_properties(hip_device):
+    """BASELINE C3 grid (128^3): single impulse reproduces the flipped bank (cross-correlation, no flip)."""
+    bank = _rand_bank(16, (9, 9, 9), 13, hip_device).contiguous()
+    x = torch.zeros(1, 1, 128, 128, 128, dtype=torch.uint8, device=hip_device)
+    x[0, 0, 64, 70, 100] = 1
+    x[0, 0, 0, 0, 0] = 1
+    x[0, 0, 127, 127, 127] = 1
+    act, _ = _hip.conv_bank(x, bank, None, want_act=True, want_out=False)
+    # out[v] = sum_t W[t] x[v + t - p]  ->  impulse at c puts W[t] at v = c - t + p  (p = 4)
+    patch = act[0, :, 60:69, 66:75, 96:105]
+    assert torch.equal(patch, bank.flip(1, 2, 3))
+    assert torch.equal(act[0, :, 0:5, 0:5, 0:5], bank.flip(1, 2, 3)[:, 4:, 4:, 4:])  # corner: zero padding
+    assert torch.equal(act[0, :, 123:, 123:, 123:], bank.flip(1, 2, 3)[:, :5, :5, :5])
+    assert act.abs().sum().item() == pytest.approx(
+        (bank.abs().sum() + bank[:, :5, :5, :5].abs().sum() + bank[:, 4:, 4:, 4:].abs().sum()).item(), rel=1e-5)

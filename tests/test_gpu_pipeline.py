@@ -1,0 +1,84 @@
+"""The drop-in modules end to end on the MI355X: SceneNet.forward and the fused point-cloud pipeline against
+the oracle (which is pinned bit-exact to the reference's forward)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from oracle import geneo_oracle as go
+from oracle import voxel_oracle as vo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _oracle_forward(model, x64):
+    names = list(model.geneos.keys())
+    specs = [(n.split("_")[0], {k: float(v) for k, v in model.geneos[n].geneo_params.items()}) for n in names]
+    lam = [float(model.lambdas_dict[f"lambda_{n}"]) for n in names]
+    last = names.index(model.last_lambda.replace("lambda_", ""))
+    ks = model.kernel_size_of_bank()
+    return go.scenenet_forward(x64, specs, ks, lam, last, return_bank=True, names=names)
+
+
+@pytest.mark.parametrize("geneo_num,ks", [({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)),
+                                          ({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)),
+                                          ({"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9)),
+                                          (None, None)])
+def test_scenenet_forward_is_the_reference_forward(hip_device, geneo_num, ks):
+    torch.manual_seed(4)
+    model = sna.SceneNet(geneo_num, ks).to(hip_device)
+    x = (torch.rand(2, 1, 24, 20, 28) < 0.08).double()
+    ref_out, ref_act = _oracle_forward(model, x)
+    out, act = model(x.to(hip_device), return_bank_activations=True)
+    assert out.dtype == torch.float64 and out.device.type == "cuda" and out.shape == x.shape
+    assert (out.cpu() - ref_out).abs().max().item() < TOL
+    assert (act.cpu() - ref_act).abs().max().item() < TOL
+    assert abs(sum(float(p) for p in model.lambdas_dict.values()) - 1.0) < 1e-6
+    # second call (last lambda was re-created by the first): same answer
+    out2 = model(x.to(hip_device))
+    assert torch.equal(out, out2)
+    # parameters changed in place (an optimiser step) are picked up
+    with torch.no_grad():
+        model.geneos["cy_0"].geneo_params["radius"].add_(0.75)
+    ref3, _ = _oracle_forward(model, x)
+    out3 = model(x.to(hip_device))
+    assert (out3.cpu() - ref3).abs().max().item() < TOL
+    assert (out3 - out).abs().max().item() > 1e-6
+
+
+def test_model_on_cpu_input_on_gpu_and_fp32_input(hip_device):
+    torch.manual_seed(6)
+    model = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (5, 5, 5))  # parameters stay on the host
+    x = (torch.rand(1, 1, 12, 12, 12) < 0.2)
+    ref, _ = _oracle_forward(model, x.double())
+    out = model(x.float().to(hip_device))
+    assert out.dtype == torch.float32
+    assert (out.double().cpu() - ref).abs().max().item() < TOL
+
+
+def test_fused_pipeline_matches_reference_chain(hip_device, golden_dir):
+    """points -> Voxelization -> ToFullDense -> SceneNet, HBM resident, vs the oracle chain."""
+    torch.manual_seed(8)
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_subset.npy"))
+    tiles = [a[:, :3]] + [vo.synthetic_tile(t, 30_000)[0] for t in range(2)]
+    labels = [a[:, 3]] + [vo.synthetic_tile(t, 30_000)[1] for t in range(2)]
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    pipe = sna.ScenePipeline(model, (64, 64, 64), keep_labels=[15])
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    out, grids = pipe(batch, want_gt=True)
+    assert out.shape == (3, 1, 64, 64, 64) and out.dtype == torch.float32
+    for b in range(3):
+        vox, gt = vo.voxelization_call((tiles[b], labels[b]), [15], None, (64, 64, 64))
+        x = torch.from_numpy(vo.to_full_dense(vox))[None]
+        assert np.array_equal(grids.occ[b].cpu().numpy(), x[0].numpy().astype(np.float32))
+        assert np.array_equal(grids.gt_occ[b].cpu().numpy(), vo.to_full_dense(gt).astype(np.float32))
+        ref, _ = _oracle_forward(model, x)
+        assert (out[b].double().cpu() - ref[0]).abs().max().item() < TOL
+
+
+def test_smoke_entry(hip_device):
+    import __graft_entry__
+    __graft_entry__.smoke()

@@ -1,0 +1,147 @@
+"""K1 parity on the MI355X: bbox / edge tables / atomic scatter / finalize (through the C ABI) against the
+numpy oracle.  The bar is BIT-EXACT: integer counts, fp64 edges, fp64 normalised density and ratio."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from scene_net_amd import _hip
+from oracle import voxel_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_tile(grids, b, xyz, labels, dims, keep):
+    counts, towers, g = vo.voxel_counts(xyz, dims, None, labels, keep)
+    nx, ny, nz = dims
+    desc = grids.desc[b].cpu().numpy()
+    assert np.array_equal(desc[:3], g["xyzmin"]) and np.array_equal(desc[3:6], g["xyzmax"])
+    edges = np.concatenate(g["segments"])
+    assert np.array_equal(desc[6:], edges), "edge table differs from numpy.linspace"
+    assert np.array_equal(grids.counts[b].cpu().numpy(), counts)
+    assert int(grids.dropped[b].item()) == 0
+    if grids.towers is not None:
+        assert np.array_equal(grids.towers[b].cpu().numpy(), towers)
+    dens = vo.normalize_xyz(counts.astype(np.float64))
+    if grids.density is not None:
+        assert np.array_equal(grids.density[b, 0].cpu().numpy(), dens)
+    if grids.occ is not None:
+        assert np.array_equal(grids.occ[b, 0].cpu().numpy(), vo.to_full_dense(dens).astype(np.float32))
+    if grids.gt is not None:
+        gt = vo.reg_on_voxel(xyz, labels, keep, dims)
+        assert np.array_equal(grids.gt[b, 0].cpu().numpy(), gt)
+        if grids.gt_occ is not None:
+            assert np.array_equal(grids.gt_occ[b, 0].cpu().numpy(), (gt > 0).astype(np.float32))
+
+
+def test_real_ts40k_tile_utm_coordinates(hip_device, golden_dir):
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_subset.npy"))
+    xyz, labels = a[:, :3], a[:, 3]
+    for dims in [(64, 64, 64), (32, 16, 48), (128, 128, 128)]:
+        batch = sna.PointBatch.from_tiles([xyz], [labels], device=hip_device)
+        g = sna.voxelize_batch(batch, dims, [15], want_density=True, want_gt=True, want_occ=True, want_gt_occ=True)
+        _check_tile(g, 0, xyz, labels, dims, [15])
+
+
+def test_ragged_batch_of_synthetic_tiles(hip_device):
+    sizes = [20_001, 36_076, 1, 2, 3, 58_243, 117_111, 64]  # odd/even offsets exercise the 16-byte peel
+    tiles, labels = zip(*[vo.synthetic_tile(t, max(n, 3))[0:2] for t, n in enumerate(sizes)])
+    tiles = [t[:n] for t, n in zip(tiles, sizes)]
+    labels = [l[:n] for l, n in zip(labels, sizes)]
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    assert batch.offsets.tolist() == np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    g = sna.voxelize_batch(batch, (64, 64, 64), [15, 16], want_density=True, want_gt=True, want_occ=True,
+                           want_gt_occ=True)
+    for b in range(len(sizes)):
+        _check_tile(g, b, tiles[b], labels[b], (64, 64, 64), [15, 16])
+        assert int(g.counts[b].sum().item()) == sizes[b]
+
+
+def test_points_on_edges_and_degenerate_axes(hip_device):
+    # lattice points sit exactly on voxel edges: the (e_k, e_{k+1}] convention decides the bin
+    ax = np.linspace(0.0, 8.0, 17)
+    lattice = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    flat = np.concatenate([lattice[:, :2], np.full((len(lattice), 1), 3.0)], 1)  # zero z-range -> cube padding
+    same = np.tile(np.array([[5.44e5, 4.634e6, 150.0]]), (50, 1))  # every point identical: all edges equal
+    shifted = lattice * 0.37 + np.array([5.44e5, 4.634e6, 150.0])
+    tiles = [lattice, flat, same, shifted]
+    batch = sna.PointBatch.from_tiles(tiles, device=hip_device)
+    for dims in [(8, 8, 8), (16, 16, 16), (5, 7, 3)]:
+        g = sna.voxelize_batch(batch, dims, want_density=True, want_occ=True)
+        for b, t in enumerate(tiles):
+            _check_tile(g, b, t, None, dims, None)
+
+
+def test_density_column_rule(hip_device):
+    # a fully occupied y-column has min > 0: its minimum cells normalise to 0 (ToFullDense -> 0)
+    rng = np.random.default_rng(2)
+    pts = []
+    for z in range(4):
+        for x in range(4):
+            for y in range(4):
+                k = 3 if y == 2 else int(rng.integers(0, 3))
+                if y == 2:
+                    k = int(rng.integers(1, 4))
+                pts += [[x + 0.5, y + 0.5, z + 0.5]] * k
+    pts += [[0.0, 0.0, 0.0], [4.0, 4.0, 4.0]]
+    xyz = np.array(pts)
+    batch = sna.PointBatch.from_tiles([xyz], device=hip_device)
+    g = sna.voxelize_batch(batch, (4, 4, 4), want_density=True, want_occ=True)
+    _check_tile(g, 0, xyz, None, (4, 4, 4), None)
+    counts = g.counts[0].cpu().numpy()
+    assert counts[:, :, 2].min() > 0
+    assert (g.occ[0, 0].cpu().numpy()[:, :, 2] == (counts[:, :, 2] > counts[:, :, 2].min())).all()
+
+
+def test_size_mode_and_reference_signatures(hip_device, golden_dir):
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_subset.npy"))
+    xyz, labels = a[:, :3], a[:, 3]
+    assert np.array_equal(sna.hist_on_voxel(xyz), vo.hist_on_voxel(xyz))
+    assert np.array_equal(sna.hist_on_voxel(xyz, (32, 32, 32)), vo.hist_on_voxel(xyz, (32, 32, 32)))
+    assert np.array_equal(sna.reg_on_voxel(xyz, labels, [15]), vo.reg_on_voxel(xyz, labels, [15]))
+    assert np.array_equal(sna.reg_on_voxel(xyz, labels, 15), vo.reg_on_voxel(xyz, labels, 15))
+    for vs in [(1.0, 1.0, 1.0), (0.5, 2.0, 1.5)]:
+        got = sna.hist_on_voxel(xyz, voxel_dims=vs)
+        ref = vo.hist_on_voxel(xyz, voxel_dims=vs)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+        assert np.array_equal(sna.reg_on_voxel(xyz, labels, [15], voxel_dims=vs),
+                              vo.reg_on_voxel(xyz, labels, [15], voxel_dims=vs))
+    vox, gt = sna.Voxelization([15], vxg_size=(64, 64, 64))((xyz, labels))
+    rv, rg = vo.voxelization_call((xyz, labels), [15], None, (64, 64, 64))
+    assert vox.shape == (1, 64, 64, 64) and vox.dtype == np.float64
+    assert np.array_equal(vox, rv) and np.array_equal(gt, rg)
+    t = sna.ToFullDense(apply=(True, True))(sna.ToTensor()((vox, gt)))
+    assert np.array_equal(t[0].numpy(), vo.to_full_dense(rv)) and np.array_equal(t[1].numpy(), vo.to_full_dense(rg))
+
+
+def test_full_size_c2_batch_properties(hip_device):
+    """BASELINE C2: 32 tiles x 100k points, 64^3.  Every tile bit-exact against the oracle (it runs in
+    milliseconds per tile) plus count conservation and run-to-run determinism of the atomics."""
+    B, N = 32, 100_000
+    tiles, labels = zip(*[vo.synthetic_tile(t, N) for t in range(B)])
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    g1 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True)
+    g2 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True)
+    assert torch.equal(g1.counts, g2.counts) and torch.equal(g1.towers, g2.towers) and torch.equal(g1.occ, g2.occ)
+    assert g1.counts.sum(dim=(1, 2, 3)).tolist() == [N] * B
+    assert int(g1.dropped.sum().item()) == 0
+    for b in range(B):
+        _check_tile(g1, b, tiles[b], labels[b], (64, 64, 64), [15])
+    # 128^3 (C3 grid) on the same clouds
+    g3 = sna.voxelize_batch(batch, (128, 128, 128), [15], want_occ=True)
+    for b in (0, 17, 31):
+        _check_tile(g3, b, tiles[b], labels[b], (128, 128, 128), [15])
+
+
+def test_unaligned_point_buffer(hip_device):
+    xyz, _ = vo.synthetic_tile(3, 5_001)
+    big = torch.zeros(5_001 * 3 + 1, dtype=torch.float64, device=hip_device)
+    view = big[1:].view(5_001, 3)  # 8-byte but not 16-byte aligned
+    view.copy_(torch.from_numpy(xyz))
+    assert view.data_ptr() % 16 == 8
+    offsets = torch.tensor([0, 5_001], dtype=torch.int64, device=hip_device)
+    batch = sna.PointBatch(view, None, offsets, (5_001,))
+    g = sna.voxelize_batch(batch, (32, 32, 32), want_occ=True)
+    _check_tile(g, 0, xyz, None, (32, 32, 32), None)

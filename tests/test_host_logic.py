@@ -1,0 +1,193 @@
+"""CPU tests of the host side: the module contract the reference's Lightning wrapper relies on
+(lit_model_wrappers.py:131-134,155,168,179), parameter packing, lambda arithmetic, sharding, and that
+nothing silently falls back to a CPU path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from scene_net_amd import _hip
+from scene_net_amd.geneos import pack_params
+from scene_net_amd.voxelization import _size_mode_bounds
+from oracle import geneo_oracle as go
+from oracle import voxel_oracle as vo
+
+
+@pytest.fixture(scope="module")
+def contract(golden_dir):
+    with open(os.path.join(golden_dir, "module_contract.json")) as f:
+        return json.load(f)
+
+
+def test_state_dict_and_accessor_names_match_reference(contract):
+    torch.manual_seed(contract["seed"])
+    m = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9))
+    assert list(m.state_dict().keys()) == contract["state_dict_keys"]
+    assert [n for n, _ in m.named_parameters()] == contract["named_parameters"]
+    assert list(m.get_geneo_params().keys()) == contract["geneo_param_names"]
+    assert list(m.get_model_parameters_in_dict().keys()) == contract["in_dict_keys"]
+    assert list(m.get_cvx_coefficients().keys()) == contract["cvx_keys"]
+    for n, p in m.named_parameters():
+        if "lambda" not in n:
+            assert p.requires_grad == contract["requires_grad"][n], n
+    assert sum(1 for n, p in m.named_parameters() if "lambda" in n and not p.requires_grad) == \
+        contract["n_frozen_lambdas"]
+    assert m.get_num_total_params() == contract["num_total_params"]
+
+
+def test_seeded_construction_draws_the_reference_values(contract):
+    torch.manual_seed(contract["seed"])
+    m = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9))
+    assert m.last_lambda == contract["seeded_last_lambda"]
+    mine = m.get_model_parameters_in_dict()
+    for k, v in contract["seeded_values"].items():
+        assert mine[k] == v, k
+    # convex: sum(lambda) == 1 after construction (SCENE_Net.py:290-291)
+    assert abs(sum(float(p) for p in m.lambdas_dict.values()) - 1.0) < 1e-6
+    # all parameters are fp32 scalars (LitWrapperModel logs .data.item())
+    for _, p in m.named_parameters():
+        assert p.dtype == torch.float32 and p.dim() == 0
+
+
+def test_default_geneo_num_and_kernel_size():
+    torch.manual_seed(0)
+    m = sna.SceneNet()
+    assert list(m.geneos.keys()) == ["cy_0", "cone_0", "neg_0"]
+    assert m.kernel_size_of_bank() == (9, 9, 9)
+    assert not hasattr(m, "kernel_size")  # only set when given (SCENE_Net.py:256-257)
+    m2 = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5))
+    assert m2.kernel_size == (9, 5, 5) and m2.kernel_size_of_bank() == (9, 5, 5)
+
+
+def test_load_reference_checkpoint_values():
+    # the 13 trained scalars of the committed Lightning checkpoint, keys without the `model.` prefix
+    sd = {"geneos.cy_0.geneo_params.radius": 0.998896, "geneos.cy_0.geneo_params.sigma": 1.199054,
+          "geneos.cone_0.geneo_params.apex": 0.0, "geneos.cone_0.geneo_params.cone_inc": 0.565547,
+          "geneos.cone_0.geneo_params.cone_radius": 4.000988, "geneos.cone_0.geneo_params.radius": 1.5,
+          "geneos.cone_0.geneo_params.sigma": 0.955910, "geneos.neg_0.geneo_params.neg_factor": 0.127053,
+          "geneos.neg_0.geneo_params.radius": 3.000918, "geneos.neg_0.geneo_params.sigma": 0.605097,
+          "lambdas_dict.lambda_cone_0": 0.608911, "lambdas_dict.lambda_cy_0": 0.024178,
+          "lambdas_dict.lambda_neg_0": 0.366911}
+    m = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5))
+    m.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    assert m.get_model_parameters_in_dict()["cone_0.cone_radius"] == pytest.approx(4.000988)
+
+
+def test_pack_params_slots():
+    p = {"radius": torch.tensor(2.0), "sigma": torch.tensor(1.5), "apex": torch.tensor(3.7),
+         "cone_radius": torch.tensor(2.5), "cone_inc": torch.tensor(0.3)}
+    v = pack_params(_hip.SN_GENEO_CONE, p, "cpu")
+    assert v.shape == (_hip.SN_NPARAM,) and v.dtype == torch.float32
+    assert v.tolist() == pytest.approx([2.0, 1.5, 3.7, 2.5, 0.3, 0.0, 0.0, 0.0])
+    v = pack_params(_hip.SN_GENEO_NEG, {"radius": 3.0, "neg_factor": 0.2}, "cpu")  # sigma defaults to 1
+    assert v.tolist() == pytest.approx([3.0, 1.0, 0.0, 0.0, 0.0, 0.2, 0.0, 0.0])
+    with pytest.raises(KeyError):
+        pack_params(_hip.SN_GENEO_CONE, {"radius": 1.0, "apex": 1.0, "cone_radius": 1.0}, "cpu")
+
+
+def test_packed_params_cache_and_apex_validation():
+    torch.manual_seed(1)
+    m = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 9, 9))
+    a, kinds = m.packed_params(torch.device("cpu"))
+    b, _ = m.packed_params(torch.device("cpu"))
+    assert a is b and kinds.tolist() == [0, 1, 2]
+    with torch.no_grad():
+        m.geneos["cy_0"].geneo_params["radius"].fill_(3.25)
+    c, _ = m.packed_params(torch.device("cpu"))
+    assert c is not a and c[0, _hip.SN_P_RADIUS].item() == 3.25
+    with torch.no_grad():
+        m.geneos["cone_0"].geneo_params["apex"].fill_(12.0)  # > kz: reference fails in torch.stack
+    with pytest.raises(RuntimeError):
+        m.packed_params(torch.device("cpu"))
+
+
+def test_effective_lambdas_matches_oracle_and_mutates_last():
+    torch.manual_seed(5)
+    m = sna.SceneNet({"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9))
+    names = list(m.geneos.keys())
+    with torch.no_grad():
+        for i, n in enumerate(names):
+            m.lambdas_dict[f"lambda_{n}"].fill_(0.013 * i - 0.07)
+    raw = [float(m.lambdas_dict[f"lambda_{n}"]) for n in names]
+    last = names.index(m.last_lambda.replace("lambda_", ""))
+    want = go.effective_lambdas(raw, last, names)
+    before = m.lambdas_dict[m.last_lambda]
+    got = m.effective_lambdas(torch.device("cpu"))
+    assert torch.equal(got, want)
+    after = m.lambdas_dict[m.last_lambda]
+    assert after is not before and not after.requires_grad  # SCENE_Net.py:333
+    assert abs(sum(float(p) for p in m.lambdas_dict.values()) - 1.0) < 1e-6
+
+
+def test_missing_mandatory_parameter_is_keyerror():
+    for cls, kw in [(sna.cylinderv2, {}), (sna.arrow, {"radius": torch.tensor(1.0)}),
+                    (sna.arrow, {"radius": torch.tensor(1.0), "apex": torch.tensor(1.0)}),
+                    (sna.negSpherev2, {"radius": torch.tensor(1.0)})]:
+        with pytest.raises(KeyError):
+            cls("g", (9, 9, 9), **kw)
+
+
+def test_no_cpu_fallback_anywhere():
+    torch.manual_seed(0)
+    m = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (5, 5, 5))
+    with pytest.raises(sna.HipLibraryError):
+        m(torch.zeros(1, 1, 8, 8, 8, dtype=torch.float64))
+    with pytest.raises(sna.HipLibraryError):
+        _hip.conv_bank(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 3, 3, 3), None, want_act=True, want_out=False)
+    if not torch.cuda.is_available():
+        with pytest.raises((sna.HipLibraryError, RuntimeError, AssertionError)):
+            sna.hist_on_voxel(np.random.rand(10, 3))
+        with pytest.raises(sna.HipLibraryError):
+            sna.cylinderv2("cy", (9, 9, 9), radius=torch.tensor(2.0))
+    # the product never imports the oracle
+    import scene_net_amd.scene_net as a, scene_net_amd.voxelization as b, scene_net_amd.geneos as c  # noqa
+    import scene_net_amd.pipeline as d, scene_net_amd.transforms as e  # noqa
+    for mod in (a, b, c, d, e, _hip):
+        src = open(mod.__file__).read()
+        assert "import oracle" not in src and "from oracle" not in src, mod.__file__
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 32, 256, 1000):
+        for w in (1, 2, 3, 8):
+            chunks = [sna.shard_range(n, r, w) for r in range(w)]
+            assert chunks[0][0] == 0 and chunks[-1][1] == n
+            for (a, b), (c, d) in zip(chunks, chunks[1:]):
+                assert b == c
+            sizes = [b - a for a, b in chunks]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sna.shard_range(4, 2, 2)
+
+
+def test_size_mode_bounds_follow_the_oracle():
+    rng = np.random.default_rng(9)
+    xyz = rng.uniform(0, 20, (400, 3)) * np.array([1.0, 0.4, 1.7]) + np.array([5.44e5, 4.634e6, 150.0])
+    for sizes in [(0.5, 0.5, 0.5), (1.0, 2.0, 0.75), (3.0, 3.0, 3.0)]:
+        g = vo.voxelgrid_compute(xyz, sizes=sizes)
+        bbox = np.concatenate([xyz.min(0), xyz.max(0)])
+        bounds, n = _size_mode_bounds(bbox, sizes)
+        assert np.array_equal(bounds[:3], g["xyzmin"]) and np.array_equal(bounds[3:], g["xyzmax"])
+        assert tuple(n) == tuple(int(v) for v in g["x_y_z"])
+
+
+def test_transforms_signatures():
+    v = sna.Voxelization([15], vxg_size=(64, 64, 64), vox_size=None)
+    assert v.keep_labels == [15] and v.vxg_size == (64, 64, 64) and v.vox_size is None
+    d = sna.ToFullDense(apply=(True, False))
+    a, b = d((torch.tensor([0.0, 0.2, 1.0]), torch.tensor([0.0, 0.3, 0.0])))
+    assert a.tolist() == [0.0, 1.0, 1.0] and b.tolist() == pytest.approx([0.0, 0.3, 0.0])
+    t = sna.ToTensor()((np.ones((1, 2, 2, 2), dtype=np.float32), np.zeros((1, 2, 2, 2))))
+    assert all(x.dtype == torch.float64 for x in t)
+
+
+def test_pointbatch_validation():
+    with pytest.raises(ValueError):
+        sna.PointBatch.from_tiles([np.zeros((4, 2))], device="cuda:0")
+    with pytest.raises(ValueError):
+        sna.PointBatch.from_tiles([np.zeros((0, 3))], device="cuda:0")
+    with pytest.raises(sna.HipLibraryError):
+        sna.PointBatch.from_tiles([np.zeros((4, 3))], device="cpu")
