@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline: voxel-tiles/s of the SCENE-Net GENEO forward hot path on MI355X.
+
+One step = one pass of the hot path over one HBM-resident batch of synthetic tiles:
+    bbox -> edge tables -> atomic scatter -> finalize (occupancy)      [K1, csrc/voxel.hip]
+    -> GENEO bank build                                                [K2, csrc/bank.hip]
+    -> bank conv on MFMA + fused convex head                           [K3, csrc/conv.hip]
+Workload = BASELINE configs[1] ("C2"): 32 tiles x 100k points, 64^3 grid, 16 GENEO kernels of 9^3, per GPU.
+Multi-GPU: one process per GPU (torchrun), tiles sharded per rank, NO data-path collective; the barrier and the
+max-over-ranks of the timed region are the only collectives (weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (K3) with its duration measured live with
+HIP events on the launch stream; `cpu_baseline` is the oracle (CPU restatement of the reference path, the only
+place this file touches oracle/) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import scene_net_amd as sna  # noqa: E402
+from scene_net_amd.pipeline import job_sum, job_time_max  # noqa: E402
+from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+GENEO_NUM = {"cy": 6, "cone": 5, "neg": 5}
+KERNEL_SIZE = (9, 9, 9)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
+    ap.add_argument("--points", type=int, default=100_000)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, specs, names, lambdas, last, budget_s=20.0):
+    """The reference path restated on the CPU (oracle/), timed on this host's cores on a bounded sample of the
+    same workload.  fp64 conv3d is what the reference runs (SCENE_Net.py:105,325); the fp32 variant is reported
+    beside it because ATen's fp64 conv3d is far off the host's own roofline."""
+    from oracle import geneo_oracle as go  # cpu_baseline leg only
+    from oracle import voxel_oracle as vo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dims = (args.grid,) * 3
+    done, t_vox, t_conv64, t_conv32 = 0, 0.0, 0.0, 0.0
+    t_start = time.perf_counter()
+    for t in range(64):
+        xyz, labels = synthetic_tile(10_000 + t, args.points)
+        t0 = time.perf_counter()
+        counts, _, _ = vo.voxel_counts(xyz, dims)
+        occ = vo.to_full_dense(vo.normalize_xyz(counts.astype(np.float64)))
+        t1 = time.perf_counter()
+        x = torch.from_numpy(occ)[None, None]
+        with torch.no_grad():
+            go.scenenet_forward(x, specs, KERNEL_SIZE, lambdas, last, names=names)
+            t2 = time.perf_counter()
+            go.scenenet_forward(x.float(), specs, KERNEL_SIZE, lambdas, last, names=names)
+            t3 = time.perf_counter()
+        if t == 0:
+            continue  # warm-up tile
+        done += 1
+        t_vox += t1 - t0
+        t_conv64 += t2 - t1
+        t_conv32 += t3 - t2
+        if time.perf_counter() - t_start > budget_s:
+            break
+    return {
+        "value": done / (t_vox + t_conv64), "unit": "tiles/s", "cores": cores, "kind": "port",
+        "sample": f"{done} tiles of the same workload (after 1 warm-up): numpy voxelisation + torch fp64 conv3d + head, "
+                  f"{cores} threads",
+        "voxel_points_per_s": done * args.points / t_vox,
+        "fp32_conv_value": done / (t_vox + t_conv32),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barrier + max/sum of scalars
+    n_gpus = world
+
+    # ---- model with explicit parameters and this rank's resident batch
+    specs, names, lambdas, last = synthetic_bank_spec(GENEO_NUM)
+    torch.manual_seed(0)
+    model = sna.SceneNet(GENEO_NUM, KERNEL_SIZE)
+    apply_bank_spec(model, specs, names, lambdas, last)
+    model = model.to(dev)
+    dims = (args.grid,) * 3
+    B = args.batch
+    tiles, labels = zip(*[synthetic_tile(rank * B + i, args.points) for i in range(B)])
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=dev)  # inputs resident in HBM before timing
+    pipe = sna.ScenePipeline(model, dims)
+    del tiles, labels
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (recorded on the launch stream)
+    conv_ev, vox_ev = [], []
+
+    def step(timed):
+        if timed:
+            a, b, c = ev(), ev(), ev()
+            a.record()
+        grids = pipe.voxelize(batch)
+        if timed:
+            b.record()
+        bank = model.compute_bank(dev)
+        lam = model.effective_lambdas(dev)
+        if timed:
+            c0 = ev()
+            c0.record()
+        _, out = sna._hip.conv_bank(grids.occ, bank, lam, want_act=False, want_out=True)
+        if timed:
+            c.record()
+            vox_ev.append((a, b))
+            conv_ev.append((c0, c))
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    fence()
+    dt_local = time.perf_counter() - t0
+    dt = job_time_max(dt_local, dev)
+    tiles_done = job_sum(float(B * args.steps), dev)
+
+    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
+    vox_ms = float(np.mean([a.elapsed_time(b) for a, b in vox_ev]))
+    V = args.grid ** 3
+    ntaps = int(np.prod(KERNEL_SIZE))
+    G = sum(GENEO_NUM.values())
+    conv_flops = 2.0 * V * ntaps * G * B                  # 6.115 GFLOP/tile @ 64^3
+    vox_bytes = (24.0 * args.points + 4.0 * V) * B        # 3.449 MB/tile @ (100k, 64^3)
+    conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12
+    vox_gbs = vox_bytes / (vox_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from a separate rocprofv3 --pmc pass
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("conv_bank_kernel", {}).get("hbm_bytes_per_launch")
+
+    res = {
+        "metric": "voxel-tiles/sec (point cloud -> 64^3 occupancy -> 16-GENEO bank conv -> head)",
+        "value": tiles_done / dt, "unit": "tiles/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2: {B} tiles/GPU x {args.points} points (fp64 xyz, UTM-scale), {args.grid}^3 voxel "
+                               f"grid, {G} GENEO kernels {KERNEL_SIZE[0]}^3 (cy 6, cone 5, neg 5), fp32 MFMA",
+                   "tiles_per_gpu": B, "points_per_tile": args.points, "grid": list(dims), "geneo_kernels": G,
+                   "kernel_size": list(KERNEL_SIZE), "parallelism": f"tile-sharded x{n_gpus}, no collectives"},
+        "points_per_s": B * args.points * n_gpus / (vox_ms * 1e-3),
+        "roofline": {"kernel": "conv_bank_kernel (K3)", "bound": "mfma", "achieved": conv_tflops,
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": traffic, "launch_ms": conv_ms, "flops_per_launch": conv_flops},
+        "roofline_voxel": {"kernel": "K1: bbox+desc+scatter+finalize (5 launches + memsets)", "bound": "hbm",
+                           "achieved": vox_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": vox_gbs / PEAK_HBM_GBS, "traffic": None, "stage_ms": vox_ms,
+                           "bytes_per_stage": vox_bytes},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, specs, names, lambdas, last)
+            res["speedup_vs_cpu_fp64"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,7 @@ this module.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -172,29 +172,3 @@ def hist_on_voxel_groupby(xyz, voxelgrid_dims=(64, 64, 64), voxel_dims=None) -> 
     for i, hist in groups.iterrows():
         data[i] = hist.iloc[0]
     return normalize_xyz(data)
-
-
-# --------------------------------------------------------------------------- #
-# synthetic tiles -- shared by tests and bench so both see the same clouds
-# --------------------------------------------------------------------------- #
-def synthetic_tile(t: int, n_points: int = 100_000) -> Tuple[np.ndarray, np.ndarray]:
-    """Tile `t` of the C2/C3 workload: (xyz [N,3] f64 at UTM-like origin, labels [N] f64)."""
-    rng = np.random.default_rng(1000 + t)
-    origin = np.array([5.44e5, 4.634e6, 1.5e2])
-    n = n_points - 2
-    n_g, n_v, n_t = int(0.60 * n), int(0.25 * n), int(0.10 * n)
-    n_l = n - n_g - n_v - n_t
-    ground = np.stack([rng.uniform(0, 30, n_g), rng.uniform(0, 30, n_g), np.abs(rng.normal(0, 0.3, n_g))], 1)
-    veg = np.stack([rng.uniform(0, 30, n_v), rng.uniform(0, 30, n_v), rng.uniform(0, 8, n_v)], 1)
-    tower = np.stack([rng.normal(15, 0.6, n_t), rng.normal(15, 0.6, n_t), rng.uniform(0, 40, n_t)], 1)
-    a, b = rng.uniform(0, 30, 2), rng.uniform(0, 30, 2)
-    s = rng.uniform(0, 1, n_l)
-    lines = np.stack([a[0] + s * (b[0] - a[0]), a[1] + s * (b[1] - a[1]), rng.normal(35, 0.5, n_l)], 1)
-    sentinels = np.array([[0.0, 0.0, 0.0], [30.0, 30.0, 60.0]])
-    xyz = np.concatenate([ground, veg, tower, lines, sentinels], 0)
-    xyz[:, :2] = np.clip(xyz[:, :2], 0, 30)
-    xyz[:, 2] = np.clip(xyz[:, 2], 0, 60)
-    labels = np.concatenate([np.full(n_g, 2.0), np.full(n_v, 4.0), np.full(n_t, 15.0), np.full(n_l, 16.0),
-                             np.full(2, 1.0)])
-    perm = rng.permutation(n_points)
-    return (xyz[perm] + origin), labels[perm]

@@ -54,10 +54,11 @@ def test_whole_bank_in_one_launch(hip_device):
                 p.update(neg_factor=float(rng.uniform(0.1, 0.9)))
             specs.append((kind, p))
     for ks in [(9, 9, 9), (9, 5, 5), (6, 5, 6), (3, 7, 4)]:
-        params = torch.stack([pack_params(KIND_OF_CLASS[k], p, hip_device) for k, p in specs]).contiguous()
-        kinds = torch.tensor([KIND_OF_CLASS[k] for k, _ in specs], dtype=torch.int32, device=hip_device)
+        sp = [(k, dict(p, apex=min(p["apex"], float(ks[0]))) if k == "cone" else p) for k, p in specs]
+        params = torch.stack([pack_params(KIND_OF_CLASS[k], p, hip_device) for k, p in sp]).contiguous()
+        kinds = torch.tensor([KIND_OF_CLASS[k] for k, _ in sp], dtype=torch.int32, device=hip_device)
         bank = _hip.geneo_bank(params, kinds, ks).cpu()
-        ref = go.geneo_bank(specs, ks)[:, 0].float()
+        ref = go.geneo_bank(sp, ks)[:, 0].float()
         assert (bank - ref).abs().max() < TOL, ks
 
 

@@ -9,6 +9,7 @@ import torch
 import scene_net_amd as sna
 from oracle import geneo_oracle as go
 from oracle import voxel_oracle as vo
+from scene_net_amd.synthetic import synthetic_tile
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -63,8 +64,8 @@ def test_fused_pipeline_matches_reference_chain(hip_device, golden_dir):
     """points -> Voxelization -> ToFullDense -> SceneNet, HBM resident, vs the oracle chain."""
     torch.manual_seed(8)
     a = np.load(os.path.join(golden_dir, "ts40k_sample575_subset.npy"))
-    tiles = [a[:, :3]] + [vo.synthetic_tile(t, 30_000)[0] for t in range(2)]
-    labels = [a[:, 3]] + [vo.synthetic_tile(t, 30_000)[1] for t in range(2)]
+    tiles = [a[:, :3]] + [synthetic_tile(t, 30_000)[0] for t in range(2)]
+    labels = [a[:, 3]] + [synthetic_tile(t, 30_000)[1] for t in range(2)]
     model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
     pipe = sna.ScenePipeline(model, (64, 64, 64), keep_labels=[15])
     batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)

@@ -9,6 +9,7 @@ import torch
 import scene_net_amd as sna
 from scene_net_amd import _hip
 from oracle import voxel_oracle as vo
+from scene_net_amd.synthetic import synthetic_tile
 
 pytestmark = pytest.mark.gpu
 
@@ -47,7 +48,7 @@ def test_real_ts40k_tile_utm_coordinates(hip_device, golden_dir):
 
 def test_ragged_batch_of_synthetic_tiles(hip_device):
     sizes = [20_001, 36_076, 1, 2, 3, 58_243, 117_111, 64]  # odd/even offsets exercise the 16-byte peel
-    tiles, labels = zip(*[vo.synthetic_tile(t, max(n, 3))[0:2] for t, n in enumerate(sizes)])
+    tiles, labels = zip(*[synthetic_tile(t, max(n, 3))[0:2] for t, n in enumerate(sizes)])
     tiles = [t[:n] for t, n in zip(tiles, sizes)]
     labels = [l[:n] for l, n in zip(labels, sizes)]
     batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
@@ -120,7 +121,7 @@ def test_full_size_c2_batch_properties(hip_device):
     """BASELINE C2: 32 tiles x 100k points, 64^3.  Every tile bit-exact against the oracle (it runs in
     milliseconds per tile) plus count conservation and run-to-run determinism of the atomics."""
     B, N = 32, 100_000
-    tiles, labels = zip(*[vo.synthetic_tile(t, N) for t in range(B)])
+    tiles, labels = zip(*[synthetic_tile(t, N) for t in range(B)])
     batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
     g1 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True)
     g2 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True)
@@ -136,7 +137,7 @@ def test_full_size_c2_batch_properties(hip_device):
 
 
 def test_unaligned_point_buffer(hip_device):
-    xyz, _ = vo.synthetic_tile(3, 5_001)
+    xyz, _ = synthetic_tile(3, 5_001)
     big = torch.zeros(5_001 * 3 + 1, dtype=torch.float64, device=hip_device)
     view = big[1:].view(5_001, 3)  # 8-byte but not 16-byte aligned
     view.copy_(torch.from_numpy(xyz))

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import voxel_oracle as vo
+from scene_net_amd.synthetic import synthetic_tile
 
 
 @pytest.fixture(scope="module")
@@ -78,8 +79,8 @@ def test_voxelization_call_shapes(real_tile):
 
 
 def test_synthetic_tile_is_deterministic_and_cubic():
-    a, la = vo.synthetic_tile(5, 10_000)
-    b, lb = vo.synthetic_tile(5, 10_000)
+    a, la = synthetic_tile(5, 10_000)
+    b, lb = synthetic_tile(5, 10_000)
     assert np.array_equal(a, b) and np.array_equal(la, lb)
     assert a.shape == (10_000, 3)
     ext = a.max(0) - a.min(0)
