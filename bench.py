@@ -49,13 +49,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the process's affinity / cgroup quota, capped at the GPU box's per-GPU
+    CPU share (16) -- oversubscribing a shared host would only slow the baseline down."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("BENCH_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(args, specs, names, lambdas, last, budget_s=20.0):
     """The reference path restated on the CPU (oracle/), timed on this host's cores on a bounded sample of the
     same workload.  fp64 conv3d is what the reference runs (SCENE_Net.py:105,325); the fp32 variant is reported
     beside it because ATen's fp64 conv3d is far off the host's own roofline."""
     from oracle import geneo_oracle as go  # cpu_baseline leg only
     from oracle import voxel_oracle as vo
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     dims = (args.grid,) * 3
     done, t_vox, t_conv64, t_conv32 = 0, 0.0, 0.0, 0.0

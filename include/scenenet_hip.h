@@ -140,6 +140,26 @@ int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_counts, int B,
                       int32_t* colstats, double* density, double* gt, float* occ, float* gt_occ,
                       sn_stream_t stream);
 
+/* Occupancy-only form of the same step, for the fused pipeline: what SceneNet consumes is
+ * ToFullDense(Voxelization(points)) (scripts/main.py:138-140), one bit per voxel.  Workgroups build the tile's
+ * bitmap in LDS (no global atomics) and the result is expanded to occ / gt_occ [B,1,nz,nx,ny] of out_dtype
+ * (SN_U8 or SN_F32); gt_occ nullable.  Needs nx*ny*nz % 32 == 0 and the bitmap(s) to fit 64 KiB of LDS
+ * (64^3 with or without gt_occ); otherwise SN_ERR_UNSUPPORTED -> use sn_voxel_scatter + sn_voxel_finalize.
+ *   bits_ws     scratch, SN_OCC_WS_WORDS(B, nx*ny*nz, planes) uint32 (planes = 2 with gt_occ, else 1)
+ *   flags       (nullable) [B] i32 out: 1 = the tile could not be proven free of a fully occupied y column
+ *               (where ToFullDense(density) != (count > 0)); such tiles are recomputed exactly by the
+ *               counting kernels when counts_ws / colstats_ws (and towers_ws with gt_occ) are given:
+ *               counts_ws, towers_ws [B,nz,nx,ny] i32, colstats_ws [B,2,ny] i32 (all nullable).
+ *   dropped     (nullable) [B] i32: points outside the edge table. */
+#define SN_OCC_PARTS 8
+#define SN_OCC_WS_WORDS(B, V, planes) ((size_t)(B) * SN_OCC_PARTS * (planes) * ((V) / 32))
+int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* offsets, int B,
+                       const double* desc, int nx, int ny, int nz,
+                       const double* keep_labels_host, int n_keep,
+                       uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
+                       int32_t* flags, int32_t* dropped,
+                       int32_t* counts_ws, int32_t* towers_ws, int32_t* colstats_ws, sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,10 @@ SYMBOLS = {
     "sn_voxel_desc_from_bounds": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "sn_voxel_scatter": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "sn_voxel_finalize": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
 }
+SN_OCC_PARTS = 8
+OCC_MAX_WORDS = 16 * 1024
 
 
 class HipLibraryError(RuntimeError):
@@ -182,3 +185,38 @@ def voxel_finalize(counts, towers, want_density=False, want_gt=False, want_occ=T
                                   nz, _ptr(colstats), _ptr(density), _ptr(gt), _ptr(occ), _ptr(gt_occ), _stream())
     _check(rc, "sn_voxel_finalize")
     return density, gt, occ, gt_occ
+
+
+def occupancy_supported(n_xyz: Sequence[int], planes: int) -> bool:
+    nx, ny, nz = (int(v) for v in n_xyz)
+    V = nx * ny * nz
+    return V % 32 == 0 and (V // 32) * planes <= OCC_MAX_WORDS
+
+
+def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[float] = (), want_gt_occ: bool = False,
+                    out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True):
+    """LDS-bitmap occupancy (sn_voxel_occupancy): returns (occ, gt_occ | None, flags, dropped), grids [B,1,nz,nx,ny]."""
+    B = offsets.numel() - 1
+    nx, ny, nz = (int(v) for v in n_xyz)
+    V = nx * ny * nz
+    dev = pts.device
+    planes = 2 if want_gt_occ else 1
+    bits = torch.empty((B * SN_OCC_PARTS * planes * (V // 32),), dtype=torch.int32, device=dev)
+    occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev)
+    gt_occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev) if want_gt_occ else None
+    flags = torch.empty((B,), dtype=torch.int32, device=dev)
+    dropped = torch.empty((B,), dtype=torch.int32, device=dev)
+    counts = towers = colstats = None
+    if exact_fallback:  # scratch for tiles whose flag is raised (gated kernels: untouched otherwise)
+        counts = torch.empty((B, V), dtype=torch.int32, device=dev)
+        towers = torch.empty((B, V), dtype=torch.int32, device=dev) if want_gt_occ else None
+        colstats = torch.empty((B, 2, ny), dtype=torch.int32, device=dev)
+    keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
+    rc = load().sn_voxel_occupancy(_ptr(pts, torch.float64, "pts"),
+                                   _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
+                                   _ptr(offsets, torch.int64, "offsets"), B, _ptr(desc, torch.float64, "desc"),
+                                   nx, ny, nz, ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
+                                   _ptr(bits), _ptr(occ), _ptr(gt_occ), _DT[out_dtype], _ptr(flags), _ptr(dropped),
+                                   _ptr(counts), _ptr(towers), _ptr(colstats), _stream())
+    _check(rc, "sn_voxel_occupancy")
+    return occ, gt_occ, flags, dropped

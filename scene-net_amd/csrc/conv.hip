@@ -29,13 +29,14 @@ constexpr int TY = 64;   // y extent of a workgroup tile
 constexpr int YP = 88;   // LDS row stride (floats): TY + up to 24 halo columns
 constexpr int NV = 8;    // accumulator tiles per wave round: 2 x-rows x 4 y-strips
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kTablePad = 2;  // extra all-zero tap steps the software pipeline may prefetch
 
 struct ConvShape {
     int B, Z, X, Y, G;
     int kz, kx, ky;
     int TZ, TX;          // workgroup tile (z, x); y is TY
     int nzt, nxt, nyt;   // tiles per axis
-    int T4;              // tap steps of 4
+    int T4;              // tap steps of 4, rounded up to even (ping-pong unroll)
 };
 
 template <typename T>
@@ -53,9 +54,10 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
 
     const int ZP = s.TZ + s.kz - 1, XP = s.TX + s.kx - 1;
     const int ntaps = s.kz * s.kx * s.ky;
-    float* Wt = lds;                                         // [T4][64]
-    int* offt = reinterpret_cast<int*>(lds + s.T4 * 64);     // [T4][4]
-    float* xs = lds + s.T4 * 64 + s.T4 * 4;                  // [ZP][XP][YP]
+    const int TT = s.T4 + kTablePad;                         // table rows incl. prefetch overrun (zero weights)
+    float* Wt = lds;                                         // [TT][64]
+    int* offt = reinterpret_cast<int*>(lds + TT * 64);       // [TT][4]
+    float* xs = lds + TT * 64 + TT * 4;                      // [ZP][XP][YP]
 
     // ---- which tile
     int bid = blockIdx.x;
@@ -66,13 +68,25 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
     const int z0 = zt * s.TZ, x0 = xt * s.TX, y0 = yt * TY;
     const int pz = (s.kz - 1) / 2, px = (s.kx - 1) / 2, py = (s.ky - 1) / 2;
 
-    // ---- stage weights: Wt[t][l] = bank[g = l&15][tap = 4t + (l>>4)]
-    for (int i = tid; i < s.T4 * 64; i += kThreads) {
-        const int t = i >> 6, l = i & 63;
-        const int g = l & 15, tap = 4 * t + (l >> 4);
-        Wt[i] = (g < s.G && tap < ntaps) ? bank[(size_t)g * ntaps + tap] : 0.0f;
+    // ---- stage weights: Wt[t][l] = bank[g = l&15][tap = 4t + (l>>4)].  Loads are issued kStage at a time
+    // so their L2 latencies overlap instead of adding up (one workgroup per CU: nothing else hides them).
+    constexpr int kStage = 8;
+    for (int base = tid; base < TT * 64; base += kThreads * kStage) {
+        float v[kStage];
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+            const int i = base + u * kThreads;
+            const int t = i >> 6, l = i & 63;
+            const int g = l & 15, tap = 4 * t + (l >> 4);
+            v[u] = (i < TT * 64 && g < s.G && tap < ntaps) ? bank[(size_t)g * ntaps + tap] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+            const int i = base + u * kThreads;
+            if (i < TT * 64) Wt[i] = v[u];
+        }
     }
-    for (int i = tid; i < s.T4 * 4; i += kThreads) {
+    for (int i = tid; i < TT * 4; i += kThreads) {
         int o = 0;
         if (i < ntaps) {
             const int dy = i % s.ky, dx = (i / s.ky) % s.kx, dz = i / (s.ky * s.kx);
@@ -80,19 +94,35 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
         }
         offt[i] = o;
     }
-    // ---- stage the zero-padded halo tile (fp32)
+    // ---- stage the zero-padded halo tile (fp32): a wave takes whole rows (row index math is wave-uniform),
+    // lanes run along y (coalesced), kStage rows in flight per wave.
     {
         const XT* xb = x + (size_t)b * s.Z * s.X * s.Y;
         const int YL = TY + s.ky - 1;
-        const int total = ZP * XP * YP;
-        for (int i = tid; i < total; i += kThreads) {
-            const int c = i % YP, r = i / YP;
-            const int xx = r % XP, zz = r / XP;
-            const int gz = z0 - pz + zz, gx = x0 - px + xx, gy = y0 - py + c;
-            float v = 0.0f;
-            if (c < YL && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
-                v = load_as_float(xb, ((size_t)gz * s.X + gx) * s.Y + gy);
-            xs[i] = v;
+        const int rows = ZP * XP;
+        const int gy0 = y0 - py + lane, gy1 = gy0 + 64;
+        const bool ok0 = (gy0 >= 0 && gy0 < s.Y);                 // lane < YL always (YL >= 64)
+        const bool ok1 = (lane + 64 < YL && gy1 >= 0 && gy1 < s.Y);
+        for (int r0 = wave; r0 < rows; r0 += kWaves * kStage) {
+            float v0[kStage], v1[kStage];
+#pragma unroll
+            for (int u = 0; u < kStage; ++u) {
+                const int r = r0 + u * kWaves;
+                const int zz = r / XP, xx = r - zz * XP;
+                const int gz = z0 - pz + zz, gx = x0 - px + xx;
+                const bool okr = (r < rows && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X);
+                const size_t rowbase = ((size_t)gz * s.X + gx) * s.Y;
+                v0[u] = (okr && ok0) ? load_as_float(xb, rowbase + gy0) : 0.0f;
+                v1[u] = (okr && ok1) ? load_as_float(xb, rowbase + gy1) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kStage; ++u) {
+                const int r = r0 + u * kWaves;
+                if (r < rows) {
+                    xs[r * YP + lane] = v0[u];
+                    if (lane + 64 < YP) xs[r * YP + lane + 64] = v1[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -118,15 +148,41 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-        for (int t = 0; t < s.T4; ++t) {
-            const float w = Wt[t * 64 + lane];
-            const float* xp = xrow + offt[t * 4 + q];
+        // Software pipeline, ping-pong unrolled by 2: while the 8 MFMAs of tap step t issue, the weight and
+        // the 8 halo-tile operands of step t+1 (and the tap offset of step t+2) are already in flight.
+        const float* wp = Wt + lane;
+        const int* op = offt + q;
+        float wa = wp[0], wb;
+        int oa = op[4], ob;  // offset of the NEXT step to load
+        float xa[NV], xb[NV];
+        {
+            const float* xp = xrow + op[0];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float xv = xp[(v >> 2) * YP + (v & 3) * 16];
-                acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, xv, acc[v], 0, 0, 0);
+            for (int v = 0; v < NV; ++v) xa[v] = xp[(v >> 2) * YP + (v & 3) * 16];
+        }
+        for (int t = 0; t < s.T4; t += 2) {
+            {   // prefetch step t+1 into (wb, xb); offset for step t+2
+                wb = wp[(t + 1) * 64];
+                ob = op[(t + 2) * 4];
+                const float* xp = xrow + oa;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) xb[v] = xp[(v >> 2) * YP + (v & 3) * 16];
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads of t+1 ahead of the MFMAs of t
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xa[v], acc[v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // prefetch step t+2 into (wa, xa); offset for step t+3
+                wa = wp[(t + 2) * 64];
+                oa = op[(t + 3) * 4];
+                const float* xp = xrow + ob;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) xa[v] = xp[(v >> 2) * YP + (v & 3) * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb, xb[v], acc[v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- epilogue
@@ -174,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
 
 size_t lds_bytes(const ConvShape& s) {
     const size_t ZP = s.TZ + s.kz - 1, XP = s.TX + s.kx - 1;
-    return ((size_t)s.T4 * 64 + (size_t)s.T4 * 4 + ZP * XP * YP) * sizeof(float);
+    const size_t TT = s.T4 + kTablePad;
+    return (TT * 64 + TT * 4 + ZP * XP * YP) * sizeof(float);
 }
 
 template <typename XT, typename OT>
@@ -211,7 +268,7 @@ extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const
 
     ConvShape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
-    s.T4 = (kz * kx * ky + 3) / 4;
+    s.T4 = (((kz * kx * ky + 3) / 4) + 1) & ~1;
     s.nyt = (Y + TY - 1) / TY;
     // largest (TZ, TX) that fits LDS and still gives the 256 CUs a few workgroups each
     static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};

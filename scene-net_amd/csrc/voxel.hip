@@ -1,13 +1,26 @@
-// K1 -- point cloud -> voxel grid: fp64 bounding box, numpy.linspace-exact edge tables,
-// per-point atomic scatter into the int32 occupancy grid, column min-max normalisation.
+// K1 -- point cloud -> voxel grid: fp64 bounding box, numpy.linspace-exact edge tables, per-point
+// scatter into the occupancy grid, column min-max normalisation.
 //
 // Follows pyntcloud 0.1.6 VoxelGrid.compute as called from utils/pcd_processing.py:341-372,
 // utils/voxelization.py:164-204 (hist_on_voxel), :244-300 (reg_on_voxel),
 // utils/pcd_processing.py:305-321 (normalize_xyz), core/datasets/torch_transforms.py:33-34.
 //
-// All box / edge arithmetic is fp64 with explicit round-to-nearest mul/add (no FMA
-// contraction) so that every edge equals numpy.linspace's bit for bit; the UTM-scale
-// coordinates (|y| ~ 4.6e6) are never narrowed.
+// All box / edge arithmetic is fp64 with explicit round-to-nearest mul/add (no FMA contraction) so
+// that every edge equals numpy.linspace's bit for bit; the UTM-scale coordinates (|y| ~ 4.6e6) are
+// never narrowed.
+//
+// Two scatter forms:
+//   * counting  (sn_voxel_scatter): one global int32 atomicAdd per point.  Needed for the density /
+//     ratio outputs.  Scattered device atomics execute at the memory side (~20 G atomics/s chip-wide
+//     on MI355X, measured), so this form is atomic-rate bound, not HBM bound.
+//   * occupancy (sn_voxel_occupancy): the network only consumes ToFullDense(density), i.e. one BIT per
+//     voxel.  Each workgroup privatises the whole tile's bitmap in LDS (64^3 bits = 32 KiB), sets
+//     bits with LDS atomics while streaming its share of the points with 16-byte loads, and writes
+//     its partial bitmap with coalesced stores; a second kernel ORs the partials and expands to the
+//     u8 / f32 grid.  No global atomics.  ToFullDense(density) is (count > column minimum), which
+//     differs from (count > 0) only if some y column is occupied in EVERY (z, x) row; the finalize
+//     kernel proves per tile that this cannot be the case (an empty row exists) or raises the tile's
+//     flag, and flagged tiles are redone by the (gated) counting kernels.
 #include "common.h"
 #include <cfloat>
 #include <climits>
@@ -16,11 +29,56 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxKeep = 16;
+constexpr int kOccThreads = 512;
+constexpr int kOccParts = SN_OCC_PARTS;
+constexpr int kMaxOccWords = 16 * 1024;  // 64 KiB of LDS bitmap per workgroup (occ + tower share it)
 
 struct KeepLabels {
     double v[kMaxKeep];
     int n;
 };
+
+__device__ __forceinline__ bool is_kept(double label, const KeepLabels& keep) {
+    bool k = false;
+    for (int i = 0; i < keep.n; ++i) k |= (label == keep.v[i]);
+    return k;
+}
+
+// ---------------------------------------------------------------- streaming a tile's points
+// Tile b owns points [p0, p1).  A thread-iteration takes TWO points = 48 contiguous bytes as three
+// 16-byte loads; an odd first point is peeled so the pairs start 16-byte aligned.  f(x, y, z, i).
+template <bool kAligned, typename F>
+__device__ __forceinline__ void for_each_point(const double* __restrict__ pts, long p0, long p1, long gtid,
+                                               long gstride, F&& f) {
+    if (kAligned) {
+        long q0 = p0 + (p0 & 1);  // first even point index >= p0
+        if (q0 > p1) q0 = p1;
+        if ((p0 & 1) && gtid == 0 && p0 < p1) f(pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2], p0);
+        const long npair = (p1 - q0) >> 1;
+        const double2* src = reinterpret_cast<const double2*>(pts + 3 * q0);
+        long i = gtid;
+        for (; i + gstride < npair; i += 2 * gstride) {  // two pairs in flight per iteration
+            const long j = i + gstride;
+            double2 a0 = src[3 * i], a1 = src[3 * i + 1], a2 = src[3 * i + 2];
+            double2 b0 = src[3 * j], b1 = src[3 * j + 1], b2 = src[3 * j + 2];
+            f(a0.x, a0.y, a1.x, q0 + 2 * i);
+            f(a1.y, a2.x, a2.y, q0 + 2 * i + 1);
+            f(b0.x, b0.y, b1.x, q0 + 2 * j);
+            f(b1.y, b2.x, b2.y, q0 + 2 * j + 1);
+        }
+        if (i < npair) {
+            double2 a0 = src[3 * i], a1 = src[3 * i + 1], a2 = src[3 * i + 2];
+            f(a0.x, a0.y, a1.x, q0 + 2 * i);
+            f(a1.y, a2.x, a2.y, q0 + 2 * i + 1);
+        }
+        if (((p1 - q0) & 1) && gtid == 0) {
+            const long k = p1 - 1;
+            f(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], k);
+        }
+    } else {
+        for (long i = p0 + gtid; i < p1; i += gstride) f(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], i);
+    }
+}
 
 // ---------------------------------------------------------------- order-preserving double <-> u64
 __device__ __forceinline__ unsigned long long enc_f64(double d) {
@@ -37,64 +95,45 @@ __global__ void bbox_init_kernel(unsigned long long* enc, int B) {
     if (i < B * 6) enc[i] = ((i % 6) < 3) ? ~0ull : 0ull;
 }
 
-struct MinMax3 {
-    double mn[3], mx[3];
-};
-
-__device__ __forceinline__ void mm_init(MinMax3& m) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        m.mn[c] = DBL_MAX;
-        m.mx[c] = -DBL_MAX;
-    }
-}
-__device__ __forceinline__ void mm_point(MinMax3& m, double x, double y, double z) {
-    m.mn[0] = fmin(m.mn[0], x); m.mx[0] = fmax(m.mx[0], x);
-    m.mn[1] = fmin(m.mn[1], y); m.mx[1] = fmax(m.mx[1], y);
-    m.mn[2] = fmin(m.mn[2], z); m.mx[2] = fmax(m.mx[2], z);
-}
-
-// Tile b owns points [p0, p1).  A thread-iteration takes TWO points = 48 contiguous bytes as
-// three 16-byte loads; an odd first point is peeled so the pairs start 16-byte aligned.
 template <bool kAligned>
 __global__ __launch_bounds__(kThreads) void bbox_reduce_kernel(const double* __restrict__ pts,
                                                                const int64_t* __restrict__ offsets,
                                                                unsigned long long* __restrict__ enc) {
+    __shared__ double red[kThreads / 64][6];
     const int b = blockIdx.y;
     const long p0 = offsets[b], p1 = offsets[b + 1];
-    MinMax3 m;
-    mm_init(m);
-    const long gtid = (long)blockIdx.x * kThreads + threadIdx.x;
-    const long gstride = (long)gridDim.x * kThreads;
-    if (kAligned) {
-        long q0 = p0 + (p0 & 1);  // first even point index >= p0
-        if (q0 > p1) q0 = p1;
-        if ((p0 & 1) && gtid == 0 && p0 < p1) mm_point(m, pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2]);
-        const long npair = (p1 - q0) >> 1;
-        const double2* src = reinterpret_cast<const double2*>(pts + 3 * q0);
-        for (long i = gtid; i < npair; i += gstride) {
-            double2 a = src[3 * i], c = src[3 * i + 1], d = src[3 * i + 2];
-            mm_point(m, a.x, a.y, c.x);
-            mm_point(m, c.y, d.x, d.y);
-        }
-        if (((p1 - q0) & 1) && gtid == 0) mm_point(m, pts[3 * (p1 - 1)], pts[3 * (p1 - 1) + 1], pts[3 * (p1 - 1) + 2]);
-    } else {
-        for (long i = p0 + gtid; i < p1; i += gstride) mm_point(m, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    }
-    // wave reduce, then one atomic per wave and slot
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for_each_point<kAligned>(pts, p0, p1, (long)blockIdx.x * kThreads + threadIdx.x, (long)gridDim.x * kThreads,
+                             [&](double x, double y, double z, long) {
+                                 mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x);
+                                 mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
+                                 mn[2] = fmin(mn[2], z); mx[2] = fmax(mx[2], z);
+                             });
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            m.mn[c] = fmin(m.mn[c], __shfl_xor(m.mn[c], o, 64));
-            m.mx[c] = fmax(m.mx[c], __shfl_xor(m.mx[c], o, 64));
+            mn[c] = fmin(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmax(mx[c], __shfl_xor(mx[c], o, 64));
         }
     }
-    if ((threadIdx.x & 63) == 0 && p1 > p0) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (m.mn[c] != DBL_MAX) atomicMin(&enc[b * 6 + c], enc_f64(m.mn[c]));
-            if (m.mx[c] != -DBL_MAX) atomicMax(&enc[b * 6 + 3 + c], enc_f64(m.mx[c]));
+            red[wave][c] = mn[c];
+            red[wave][3 + c] = mx[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && p1 > p0) {  // one atomic per workgroup and slot
+        const int c = threadIdx.x;
+        double v = red[0][c];
+        for (int w = 1; w < kThreads / 64; ++w) v = (c < 3) ? fmin(v, red[w][c]) : fmax(v, red[w][c]);
+        if (c < 3) {
+            if (v != DBL_MAX) atomicMin(&enc[b * 6 + c], enc_f64(v));
+        } else {
+            if (v != -DBL_MAX) atomicMax(&enc[b * 6 + c], enc_f64(v));
         }
     }
 }
@@ -150,7 +189,7 @@ __global__ void desc_kernel(const double* __restrict__ box, int nx, int ny, int 
     }
 }
 
-// ---------------------------------------------------------------- scatter
+// ---------------------------------------------------------------- binning
 // largest j with e[j] < p  (== numpy.searchsorted(e, p, side='left') - 1), in [-1, n]
 __device__ __forceinline__ int bin_axis(double p, const double* e, int n, double lo, double inv_step) {
     double f = (p - lo) * inv_step;
@@ -160,31 +199,48 @@ __device__ __forceinline__ int bin_axis(double p, const double* e, int n, double
     return k;
 }
 
-struct ScatterCtx {
+struct Binner {
     const double *ex, *ey, *ez;
     double lo[3], inv[3];
     int nx, ny, nz;
-    int32_t* counts;
-    int32_t* towers;
+
+    // edges must already sit in LDS at `edges`; d = this tile's descriptor
+    __device__ __forceinline__ void init(const double* edges, const double* d, int nx_, int ny_, int nz_) {
+        ex = edges; ey = edges + nx_ + 1; ez = edges + nx_ + ny_ + 2;
+        nx = nx_; ny = ny_; nz = nz_;
+        const int n[3] = {nx_, ny_, nz_};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = d[a];
+            double step = (d[3 + a] - d[a]) / (double)n[a];
+            inv[a] = (step > 0.0) ? 1.0 / step : 0.0;
+        }
+    }
+    // flat [z][x][y] index, or -1 when the point is NaN / outside the edge table (np.clip to n)
+    __device__ __forceinline__ int flat(double x, double y, double z) const {
+        if (x != x || y != y || z != z) return -1;
+        int ix = max(bin_axis(x, ex, nx, lo[0], inv[0]), 0);
+        int iy = max(bin_axis(y, ey, ny, lo[1], inv[1]), 0);
+        int iz = max(bin_axis(z, ez, nz, lo[2], inv[2]), 0);
+        if (ix >= nx || iy >= ny || iz >= nz) return -1;
+        return (iz * nx + ix) * ny + iy;
+    }
 };
 
-__device__ __forceinline__ void scatter_point(const ScatterCtx& c, double x, double y, double z, bool tower,
-                                              int& dropped) {
-    if (x != x || y != y || z != z) { ++dropped; return; }
-    int ix = bin_axis(x, c.ex, c.nx, c.lo[0], c.inv[0]);
-    int iy = bin_axis(y, c.ey, c.ny, c.lo[1], c.inv[1]);
-    int iz = bin_axis(z, c.ez, c.nz, c.lo[2], c.inv[2]);
-    ix = max(ix, 0); iy = max(iy, 0); iz = max(iz, 0);  // np.clip(., 0, n)
-    if (ix >= c.nx || iy >= c.ny || iz >= c.nz) { ++dropped; return; }  // index n: outside the table
-    int flat = (iz * c.nx + ix) * c.ny + iy;
-    atomicAdd(&c.counts[flat], 1);
-    if (tower) atomicAdd(&c.towers[flat], 1);
+__device__ __forceinline__ void load_edges(double* edges, const double* d, int ne, int nthreads) {
+    for (int i = threadIdx.x; i < ne; i += nthreads) edges[i] = d[6 + i];
+    __syncthreads();
 }
 
-__device__ __forceinline__ bool is_kept(double label, const KeepLabels& keep) {
-    bool k = false;
-    for (int i = 0; i < keep.n; ++i) k |= (label == keep.v[i]);
-    return k;
+// ---------------------------------------------------------------- counting scatter (global atomics)
+__global__ void gated_zero_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b2, size_t V,
+                                  const int32_t* __restrict__ gate) {
+    const int b = blockIdx.y;
+    if (gate && !gate[b]) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x) {
+        a[(size_t)b * V + i] = 0;
+        if (b2) b2[(size_t)b * V + i] = 0;
+    }
 }
 
 template <bool kAligned>
@@ -194,68 +250,134 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const double* __restr
                                                            const double* __restrict__ desc, int nx, int ny, int nz,
                                                            int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ towers, KeepLabels keep,
-                                                           int32_t* __restrict__ dropped_out) {
+                                                           int32_t* __restrict__ dropped_out,
+                                                           const int32_t* __restrict__ gate) {
     extern __shared__ double edges[];  // [nx+1 + ny+1 + nz+1]
     const int b = blockIdx.y;
-    const int len = SN_DESC_LEN(nx, ny, nz);
-    const double* d = desc + (size_t)b * len;
-    const int ne = nx + ny + nz + 3;
-    for (int i = threadIdx.x; i < ne; i += kThreads) edges[i] = d[6 + i];
-    __syncthreads();
-
-    ScatterCtx c;
-    c.ex = edges; c.ey = edges + nx + 1; c.ez = edges + nx + ny + 2;
-    c.nx = nx; c.ny = ny; c.nz = nz;
-    const int n[3] = {nx, ny, nz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        c.lo[a] = d[a];
-        double step = (d[3 + a] - d[a]) / (double)n[a];
-        c.inv[a] = (step > 0.0) ? 1.0 / step : 0.0;
-    }
+    if (gate && !gate[b]) return;
+    const double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+    load_edges(edges, d, nx + ny + nz + 3, kThreads);
+    Binner bin;
+    bin.init(edges, d, nx, ny, nz);
     const size_t V = (size_t)nx * ny * nz;
-    c.counts = counts + (size_t)b * V;
-    c.towers = towers ? towers + (size_t)b * V : nullptr;
+    int32_t* c = counts + (size_t)b * V;
+    int32_t* t = towers ? towers + (size_t)b * V : nullptr;
     const bool want_tower = (towers != nullptr) && (labels != nullptr);
-
-    const long p0 = offsets[b], p1 = offsets[b + 1];
-    const long gtid = (long)blockIdx.x * kThreads + threadIdx.x;
-    const long gstride = (long)gridDim.x * kThreads;
     int dropped = 0;
-    if (kAligned) {
-        long q0 = p0 + (p0 & 1);
-        if (q0 > p1) q0 = p1;
-        if ((p0 & 1) && gtid == 0 && p0 < p1)
-            scatter_point(c, pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2], want_tower && is_kept(labels[p0], keep),
-                          dropped);
-        const long npair = (p1 - q0) >> 1;
-        const double2* src = reinterpret_cast<const double2*>(pts + 3 * q0);
-        const double2* lsrc = want_tower ? reinterpret_cast<const double2*>(labels + q0) : nullptr;
-        for (long i = gtid; i < npair; i += gstride) {
-            double2 u = src[3 * i], v = src[3 * i + 1], w = src[3 * i + 2];
-            bool t0 = false, t1 = false;
-            if (want_tower) {
-                double2 l = lsrc[i];
-                t0 = is_kept(l.x, keep);
-                t1 = is_kept(l.y, keep);
-            }
-            scatter_point(c, u.x, u.y, v.x, t0, dropped);
-            scatter_point(c, v.y, w.x, w.y, t1, dropped);
-        }
-        if (((p1 - q0) & 1) && gtid == 0) {
-            long i = p1 - 1;
-            scatter_point(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], want_tower && is_kept(labels[i], keep),
-                          dropped);
-        }
-    } else {
-        for (long i = p0 + gtid; i < p1; i += gstride)
-            scatter_point(c, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], want_tower && is_kept(labels[i], keep),
-                          dropped);
-    }
+    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kThreads + threadIdx.x,
+                             (long)gridDim.x * kThreads, [&](double x, double y, double z, long i) {
+                                 const int f = bin.flat(x, y, z);
+                                 if (f < 0) { ++dropped; return; }
+                                 atomicAdd(&c[f], 1);
+                                 if (want_tower && is_kept(labels[i], keep)) atomicAdd(&t[f], 1);
+                             });
     if (dropped_out && dropped) atomicAdd(&dropped_out[b], dropped);
 }
 
-// ---------------------------------------------------------------- finalize
+// ---------------------------------------------------------------- occupancy bitmap (LDS atomics)
+// grid (kOccParts, B).  LDS: edge table, then `words` of occupancy bits, then (optionally) `words`
+// of tower bits.  part p of tile b writes bits_ws[(b*kOccParts + p) * planes * words ...].
+template <bool kAligned>
+__global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* __restrict__ pts,
+                                                                  const double* __restrict__ labels,
+                                                                  const int64_t* __restrict__ offsets,
+                                                                  const double* __restrict__ desc, int nx, int ny,
+                                                                  int nz, int words, int planes, KeepLabels keep,
+                                                                  uint32_t* __restrict__ bits_ws,
+                                                                  int32_t* __restrict__ dropped_out,
+                                                                  int32_t* __restrict__ flags) {
+    extern __shared__ double smem[];
+    const int ne = nx + ny + nz + 3;
+    double* edges = smem;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(smem + ((ne + 1) & ~1));  // 16-byte aligned
+    const int b = blockIdx.y;
+    const double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+    for (int i = threadIdx.x; i < words * planes; i += kOccThreads) bits[i] = 0u;
+    load_edges(edges, d, ne, kOccThreads);  // ends with __syncthreads()
+    Binner bin;
+    bin.init(edges, d, nx, ny, nz);
+    const bool want_tower = (planes == 2);
+    int dropped = 0;
+    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kOccThreads + threadIdx.x,
+                             (long)gridDim.x * kOccThreads, [&](double x, double y, double z, long i) {
+                                 const int f = bin.flat(x, y, z);
+                                 if (f < 0) { ++dropped; return; }
+                                 atomicOr(&bits[f >> 5], 1u << (f & 31));
+                                 if (want_tower && is_kept(labels[i], keep))
+                                     atomicOr(&bits[words + (f >> 5)], 1u << (f & 31));
+                             });
+    __syncthreads();
+    uint32_t* out = bits_ws + ((size_t)b * kOccParts + blockIdx.x) * (size_t)planes * words;
+    for (int i = threadIdx.x; i < words * planes; i += kOccThreads) out[i] = bits[i];
+    if (dropped_out && dropped) atomicAdd(&dropped_out[b], dropped);
+    if (flags && blockIdx.x == 0 && threadIdx.x == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
+}
+
+// OR of the kOccParts partial bitmaps of one tile (plane 0 = occupancy, 1 = towers), word w
+__device__ __forceinline__ uint32_t merged_word(const uint32_t* __restrict__ src, int planes, int words, int plane,
+                                                long w) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int p = 0; p < kOccParts; ++p) m |= src[((size_t)p * planes + plane) * words + w];
+    return m;
+}
+
+template <typename OT>
+__device__ __forceinline__ void expand_word(uint32_t m, OT* __restrict__ dst);
+
+// 32 bits -> 32 bytes {0,1}: (nibble * 0x00204081) & 0x01010101 spreads 4 bits over 4 bytes
+template <>
+__device__ __forceinline__ void expand_word<uint8_t>(uint32_t m, uint8_t* __restrict__ dst) {
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (((m >> (4 * k)) & 0xFu) * 0x00204081u) & 0x01010101u;
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+template <>
+__device__ __forceinline__ void expand_word<float>(uint32_t m, float* __restrict__ dst) {
+    float4* d = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        d[k] = make_float4((float)((m >> (4 * k)) & 1u), (float)((m >> (4 * k + 1)) & 1u),
+                           (float)((m >> (4 * k + 2)) & 1u), (float)((m >> (4 * k + 3)) & 1u));
+}
+
+// grid (C, B): OR the partial bitmaps, expand bits to the u8 / f32 grids (one 32-voxel word per thread
+// iteration, 16-byte stores), and prove "no y column is full" (an empty (z,x) row exists) -- the tile's
+// flag was raised by occ_partial_kernel and is cleared here by whoever finds an empty row.
+template <typename OT>
+__global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* __restrict__ bits_ws, int words,
+                                                                int planes, int rows, int ny, size_t V,
+                                                                OT* __restrict__ occ, OT* __restrict__ gt_occ,
+                                                                int32_t* __restrict__ flags) {
+    const int b = blockIdx.y;
+    const uint32_t* src = bits_ws + (size_t)b * kOccParts * planes * words;
+    const int gtid = blockIdx.x * kThreads + threadIdx.x, gstride = gridDim.x * kThreads;
+    for (int w = gtid; w < words; w += gstride) {
+        expand_word<OT>(merged_word(src, planes, words, 0, w), occ + (size_t)b * V + (size_t)w * 32);
+        if (gt_occ) expand_word<OT>(merged_word(src, planes, words, 1, w), gt_occ + (size_t)b * V + (size_t)w * 32);
+    }
+    if (!flags) return;
+    // row r owns bits [r*ny, (r+1)*ny)
+    bool empty = false;
+    for (int r = gtid; r < rows && !empty; r += gstride) {
+        const long lo = (long)r * ny, hi = lo + ny;
+        uint32_t any = 0u;
+        for (long w = lo >> 5; w <= (hi - 1) >> 5; ++w) {
+            uint32_t m = merged_word(src, planes, words, 0, w);
+            const long wlo = w << 5;
+            if (lo > wlo) m &= ~0u << (lo - wlo);
+            if (hi < wlo + 32) m &= ~0u >> (wlo + 32 - hi);
+            any |= m;
+        }
+        empty = (any == 0u);
+    }
+    if (empty) flags[b] = 0;  // benign race: every writer stores 0
+}
+
+// ---------------------------------------------------------------- finalize (counting path)
 __global__ void colstats_init_kernel(int32_t* cs, int B, int ny) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * 2 * ny) cs[i] = (((i / ny) & 1) == 0) ? INT_MAX : 0;
@@ -264,8 +386,10 @@ __global__ void colstats_init_kernel(int32_t* cs, int B, int ny) {
 // grid (S, B): block s takes rows r = s, s+S, ... of the [nz*nx, ny] count matrix of tile b;
 // threads run along y (coalesced), kThreads/ny' row lanes deep.
 __global__ __launch_bounds__(kThreads) void colstats_kernel(const int32_t* __restrict__ counts, int rows, int ny,
-                                                            int32_t* __restrict__ cs) {
+                                                            int32_t* __restrict__ cs,
+                                                            const int32_t* __restrict__ gate) {
     const int b = blockIdx.y;
+    if (gate && !gate[b]) return;
     const int32_t* c = counts + (size_t)b * rows * ny;
     for (int y0 = 0; y0 < ny; y0 += kThreads) {
         const int width = min(ny - y0, kThreads);
@@ -285,16 +409,20 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const int32_t* __res
     }
 }
 
+// grid (blocks, B)
+template <typename OT>
 __global__ __launch_bounds__(kThreads) void finalize_kernel(const int32_t* __restrict__ counts,
                                                             const int32_t* __restrict__ towers,
-                                                            const int32_t* __restrict__ cs, size_t total, size_t V,
-                                                            int ny, double* __restrict__ density,
-                                                            double* __restrict__ gt, float* __restrict__ occ,
-                                                            float* __restrict__ gt_occ) {
+                                                            const int32_t* __restrict__ cs, size_t V, int ny,
+                                                            double* __restrict__ density, double* __restrict__ gt,
+                                                            OT* __restrict__ occ, OT* __restrict__ gt_occ,
+                                                            const int32_t* __restrict__ gate) {
+    const int b = blockIdx.y;
+    if (gate && !gate[b]) return;
     const size_t stride = (size_t)gridDim.x * kThreads;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
-        const int b = (int)(i / V);
-        const int y = (int)(i % ny);
+    for (size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x; v < V; v += stride) {
+        const size_t i = (size_t)b * V + v;
+        const int y = (int)(v % ny);
         const int c = counts[i];
         if (density || occ) {
             // sklearn MinMaxScaler: scale = 1/range (range < 10 eps -> 1); X*scale + (0 - min*scale)
@@ -303,23 +431,67 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const int32_t* __res
             if (rng < 10.0 * DBL_EPSILON) rng = 1.0;
             const double scale = __ddiv_rn(1.0, rng);
             const double min_ = __dsub_rn(0.0, __dmul_rn((double)mn, scale));
-            const double v = __dadd_rn(__dmul_rn((double)c, scale), min_);
-            if (density) density[i] = v;
-            if (occ) occ[i] = (v > 0.0) ? 1.0f : 0.0f;
+            const double val = __dadd_rn(__dmul_rn((double)c, scale), min_);
+            if (density) density[i] = val;
+            if (occ) occ[i] = (val > 0.0) ? (OT)1 : (OT)0;
         }
         if (gt || gt_occ) {
             const int t = towers[i];
             const double r = (c > 0) ? __ddiv_rn((double)t, (double)c) : 0.0;
             if (gt) gt[i] = r;
-            if (gt_occ) gt_occ[i] = (r > 0.0) ? 1.0f : 0.0f;
+            if (gt_occ) gt_occ[i] = (r > 0.0) ? (OT)1 : (OT)0;
         }
     }
 }
 
-inline int blocks_per_tile(int B) {
-    // enough workgroups to fill 256 CUs a few times over, whatever the batch
-    int per = (2048 + B - 1) / B;
+inline int blocks_per_tile(int B, int target) {
+    int per = (target + B - 1) / B;
     return per < 1 ? 1 : (per > 256 ? 256 : per);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int fill_keep(KeepLabels& keep, const double* keep_labels_host, int n_keep) {
+    if (n_keep < 0 || n_keep > kMaxKeep) return -1;
+    keep.n = n_keep;
+    for (int i = 0; i < kMaxKeep; ++i) keep.v[i] = (i < n_keep) ? keep_labels_host[i] : 0.0;
+    return 0;
+}
+
+// counting scatter + colstats + finalize, optionally gated per tile; shared by sn_voxel_scatter /
+// sn_voxel_finalize / the fallback of sn_voxel_occupancy
+void launch_scatter(const double* pts, const double* labels, const int64_t* offsets, int B, const double* desc,
+                    int nx, int ny, int nz, int32_t* counts, int32_t* towers, const KeepLabels& keep,
+                    int32_t* dropped, const int32_t* gate, hipStream_t s) {
+    const size_t V = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(gated_zero_kernel, dim3(64, B), dim3(256), 0, s, counts, towers, V, gate);
+    const size_t lds = (size_t)(nx + ny + nz + 3) * sizeof(double);
+    dim3 grid(blocks_per_tile(B, 1024), B);
+    const bool al = aligned16(pts);
+    if (al)
+        hipLaunchKernelGGL(scatter_kernel<true>, grid, dim3(kThreads), lds, s, pts, labels, offsets, desc, nx, ny, nz,
+                           counts, towers, keep, dropped, gate);
+    else
+        hipLaunchKernelGGL(scatter_kernel<false>, grid, dim3(kThreads), lds, s, pts, labels, offsets, desc, nx, ny,
+                           nz, counts, towers, keep, dropped, gate);
+}
+
+template <typename OT>
+void launch_finalize(const int32_t* counts, const int32_t* towers, int B, int nx, int ny, int nz, int32_t* colstats,
+                     double* density, double* gt, OT* occ, OT* gt_occ, const int32_t* gate, hipStream_t s) {
+    const size_t V = (size_t)nx * ny * nz;
+    if (density || occ) {
+        hipLaunchKernelGGL(colstats_init_kernel, dim3((B * 2 * ny + 255) / 256), dim3(256), 0, s, colstats, B, ny);
+        const int rows = nz * nx;
+        int S = (rows + 63) / 64;
+        if (S > 64) S = 64;
+        hipLaunchKernelGGL(colstats_kernel, dim3(S, B), dim3(kThreads), 0, s, counts, rows, ny, colstats, gate);
+    }
+    size_t blocks = (V + kThreads - 1) / kThreads;
+    const size_t cap = (size_t)blocks_per_tile(B, 4096);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(finalize_kernel<OT>, dim3((unsigned)blocks, B), dim3(kThreads), 0, s, counts, towers, colstats,
+                       V, ny, density, gt, occ, gt_occ, gate);
 }
 
 }  // namespace
@@ -330,8 +502,8 @@ extern "C" int sn_voxel_bbox(const double* pts, const int64_t* offsets, int B, d
     hipStream_t s = sn::as_stream(stream);
     auto* enc = reinterpret_cast<unsigned long long*>(bbox);
     hipLaunchKernelGGL(bbox_init_kernel, dim3((B * 6 + 255) / 256), dim3(256), 0, s, enc, B);
-    dim3 grid(blocks_per_tile(B), B);
-    if ((reinterpret_cast<uintptr_t>(pts) & 15) == 0)
+    dim3 grid(blocks_per_tile(B, 1024), B);
+    if (aligned16(pts))
         hipLaunchKernelGGL(bbox_reduce_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, enc);
     else
         hipLaunchKernelGGL(bbox_reduce_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, enc);
@@ -365,31 +537,18 @@ extern "C" int sn_voxel_scatter(const double* pts, const double* labels, const i
     if (!pts || !offsets || !desc || !counts) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_scatter: null pointer");
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_scatter: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny, nz);
-    if (n_keep < 0 || n_keep > kMaxKeep)
-        return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_scatter: n_keep=%d outside [0,%d]", n_keep, kMaxKeep);
-    if (tower_counts && (!labels || (n_keep > 0 && !keep_labels_host)))
+    KeepLabels keep;
+    if (fill_keep(keep, keep_labels_host, (n_keep > 0 && !keep_labels_host) ? -1 : n_keep))
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_scatter: n_keep=%d outside [0,%d] or null list", n_keep,
+                        kMaxKeep);
+    if (tower_counts && !labels)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_scatter: tower_counts needs labels and keep_labels_host");
-    const size_t lds = (size_t)(nx + ny + nz + 3) * sizeof(double);
-    if (lds > 64 * 1024) return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_scatter: edge table %zu B > 64 KiB", lds);
+    if ((size_t)(nx + ny + nz + 3) * sizeof(double) > 64 * 1024)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_scatter: edge table > 64 KiB");
     hipStream_t s = sn::as_stream(stream);
-    const size_t bytes = (size_t)B * nx * ny * nz * sizeof(int32_t);
-    if (hipMemsetAsync(counts, 0, bytes, s) != hipSuccess) return sn::check_launch("sn_voxel_scatter(memset)");
-    if (tower_counts && hipMemsetAsync(tower_counts, 0, bytes, s) != hipSuccess)
-        return sn::check_launch("sn_voxel_scatter(memset)");
     if (dropped && hipMemsetAsync(dropped, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess)
         return sn::check_launch("sn_voxel_scatter(memset)");
-    KeepLabels keep;
-    keep.n = n_keep;
-    for (int i = 0; i < kMaxKeep; ++i) keep.v[i] = (i < n_keep) ? keep_labels_host[i] : 0.0;
-    dim3 grid(blocks_per_tile(B), B);
-    const bool aligned = ((reinterpret_cast<uintptr_t>(pts) & 15) == 0) &&
-                         (!labels || (reinterpret_cast<uintptr_t>(labels) & 15) == 0);
-    if (aligned)
-        hipLaunchKernelGGL(scatter_kernel<true>, grid, dim3(kThreads), lds, s, pts, labels, offsets, desc, nx, ny, nz,
-                           counts, tower_counts, keep, dropped);
-    else
-        hipLaunchKernelGGL(scatter_kernel<false>, grid, dim3(kThreads), lds, s, pts, labels, offsets, desc, nx, ny,
-                           nz, counts, tower_counts, keep, dropped);
+    launch_scatter(pts, labels, offsets, B, desc, nx, ny, nz, counts, tower_counts, keep, dropped, nullptr, s);
     return sn::check_launch("sn_voxel_scatter");
 }
 
@@ -403,19 +562,70 @@ extern "C" int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_cou
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_finalize: gt outputs need tower_counts");
     if ((density || occ) && !colstats)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_finalize: density/occ need the colstats workspace");
-    hipStream_t s = sn::as_stream(stream);
-    const size_t V = (size_t)nx * ny * nz;
-    if (density || occ) {
-        hipLaunchKernelGGL(colstats_init_kernel, dim3((B * 2 * ny + 255) / 256), dim3(256), 0, s, colstats, B, ny);
-        const int rows = nz * nx;
-        int S = (rows + 63) / 64;
-        if (S > 64) S = 64;
-        hipLaunchKernelGGL(colstats_kernel, dim3(S, B), dim3(kThreads), 0, s, counts, rows, ny, colstats);
-    }
-    const size_t total = (size_t)B * V;
-    size_t blocks = (total + kThreads - 1) / kThreads;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, counts, tower_counts, colstats,
-                       total, V, ny, density, gt, occ, gt_occ);
+    launch_finalize<float>(counts, tower_counts, B, nx, ny, nz, colstats, density, gt, occ, gt_occ, nullptr,
+                           sn::as_stream(stream));
     return sn::check_launch("sn_voxel_finalize");
+}
+
+extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* offsets, int B,
+                                  const double* desc, int nx, int ny, int nz, const double* keep_labels_host,
+                                  int n_keep, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
+                                  int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
+                                  int32_t* colstats_ws, sn_stream_t stream) {
+    if (!pts || !offsets || !desc || !bits_ws || !occ)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: null pointer");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny,
+                        nz);
+    if (out_dtype != SN_U8 && out_dtype != SN_F32)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: out_dtype %d (SN_U8 | SN_F32)", out_dtype);
+    const int planes = gt_occ ? 2 : 1;
+    if (gt_occ && !labels) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: gt_occ needs labels");
+    KeepLabels keep;
+    if (fill_keep(keep, keep_labels_host, (n_keep > 0 && !keep_labels_host) ? -1 : n_keep))
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_occupancy: n_keep=%d outside [0,%d] or null list", n_keep,
+                        kMaxKeep);
+    const size_t V = (size_t)nx * ny * nz;
+    if (V % 32 != 0 || (V / 32) * planes > (size_t)kMaxOccWords)
+        return sn::fail(SN_ERR_UNSUPPORTED,
+                        "sn_voxel_occupancy: %zu voxels x %d planes do not fit the 64 KiB LDS bitmap "
+                        "(use sn_voxel_scatter + sn_voxel_finalize)", V, planes);
+    if (gt_occ && flags && counts_ws && !towers_ws)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: the counting fallback needs towers_ws for gt_occ");
+    const int words = (int)(V / 32);
+    const int ne = nx + ny + nz + 3;
+    hipStream_t s = sn::as_stream(stream);
+    if (dropped && hipMemsetAsync(dropped, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess)
+        return sn::check_launch("sn_voxel_occupancy(memset)");
+    const size_t lds1 = (size_t)((ne + 1) & ~1) * sizeof(double) + (size_t)words * planes * sizeof(uint32_t);
+    const bool al = aligned16(pts);
+    {
+        auto kern = al ? occ_partial_kernel<true> : occ_partial_kernel<false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess)
+            return sn::check_launch("sn_voxel_occupancy(hipFuncSetAttribute)");
+        hipLaunchKernelGGL(kern, dim3(kOccParts, B), dim3(kOccThreads), lds1, s, pts, labels, offsets, desc, nx, ny,
+                           nz, words, planes, keep, bits_ws, dropped, flags);
+    }
+    const int rows = nz * nx;
+    int C = (words + kThreads - 1) / kThreads;
+    if (C > blocks_per_tile(B, 2048)) C = blocks_per_tile(B, 2048);
+    if (out_dtype == SN_U8)
+        hipLaunchKernelGGL(occ_finalize_kernel<uint8_t>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes,
+                           rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags);
+    else
+        hipLaunchKernelGGL(occ_finalize_kernel<float>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes, rows,
+                           ny, V, (float*)occ, (float*)gt_occ, flags);
+    // flagged tiles (a y column might be full): redo exactly through the counting kernels, gated per tile
+    if (flags && counts_ws && colstats_ws) {
+        launch_scatter(pts, gt_occ ? labels : nullptr, offsets, B, desc, nx, ny, nz, counts_ws,
+                       gt_occ ? towers_ws : nullptr, keep, nullptr, flags, s);
+        if (out_dtype == SN_U8)
+            launch_finalize<uint8_t>(counts_ws, towers_ws, B, nx, ny, nz, colstats_ws, nullptr, nullptr,
+                                     (uint8_t*)occ, (uint8_t*)gt_occ, flags, s);
+        else
+            launch_finalize<float>(counts_ws, towers_ws, B, nx, ny, nz, colstats_ws, nullptr, nullptr, (float*)occ,
+                                   (float*)gt_occ, flags, s);
+    }
+    return sn::check_launch("sn_voxel_occupancy");
 }

@@ -64,14 +64,15 @@ class PointBatch:
 
 @dataclass
 class VoxelGrids:
-    counts: torch.Tensor                 # [B,nz,nx,ny] i32
+    counts: Optional[torch.Tensor]       # [B,nz,nx,ny] i32 (None on the occupancy-only path)
     towers: Optional[torch.Tensor]       # [B,nz,nx,ny] i32
     density: Optional[torch.Tensor]      # [B,1,nz,nx,ny] f64  hist_on_voxel
     gt: Optional[torch.Tensor]           # [B,1,nz,nx,ny] f64  reg_on_voxel
-    occ: Optional[torch.Tensor]          # [B,1,nz,nx,ny] f32  ToFullDense(density)
-    gt_occ: Optional[torch.Tensor]       # [B,1,nz,nx,ny] f32  ToFullDense(gt)
+    occ: Optional[torch.Tensor]          # [B,1,nz,nx,ny] f32|u8  ToFullDense(density)
+    gt_occ: Optional[torch.Tensor]       # [B,1,nz,nx,ny] f32|u8  ToFullDense(gt)
     desc: torch.Tensor                   # [B, 6+nx+ny+nz+3] f64: lo, hi, edges
     dropped: torch.Tensor                # [B] i32
+    flags: Optional[torch.Tensor] = None  # [B] i32, occupancy path: tiles redone by the counting kernels
 
 
 def _labels_list(tower_label) -> List[float]:
@@ -81,9 +82,14 @@ def _labels_list(tower_label) -> List[float]:
 def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 64),
                    keep_labels: Optional[Sequence[float]] = None, want_density: bool = False,
                    want_gt: bool = False, want_occ: bool = True, want_gt_occ: bool = False,
-                   bounds: Optional[torch.Tensor] = None) -> VoxelGrids:
+                   bounds: Optional[torch.Tensor] = None, want_counts: bool = False,
+                   occ_dtype: torch.dtype = torch.float32) -> VoxelGrids:
     """n_x/n_y/n_z mode of voxelize_ply for a whole batch.  `voxelgrid_dims` is (x, y, z) like the
-    reference (pcd_processing.py:362-363); grids come back [.., nz, nx, ny] (voxelization.py:193)."""
+    reference (pcd_processing.py:362-363); grids come back [.., nz, nx, ny] (voxelization.py:193).
+
+    When only the binary grids are wanted (what SceneNet consumes) and the tile's bitmap fits LDS, the
+    occupancy kernels run (LDS atomics, no global atomics); the density / ratio / count outputs take the
+    counting kernels."""
     nx, ny, nz = (int(v) for v in voxelgrid_dims)
     want_t = (want_gt or want_gt_occ)
     if want_t and (batch.labels is None or keep_labels is None):
@@ -93,10 +99,22 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
         desc = _hip.voxel_desc(bbox, (nx, ny, nz), regular=True)
     else:
         desc = _hip.voxel_desc(bounds, (nx, ny, nz), from_bounds=True)
+    occupancy_only = (want_occ and not (want_density or want_gt or want_counts)
+                      and _hip.occupancy_supported((nx, ny, nz), 2 if want_gt_occ else 1))
+    if occupancy_only:
+        occ, gt_occ, flags, dropped = _hip.voxel_occupancy(batch.pts, batch.labels if want_t else None,
+                                                           batch.offsets, desc, (nx, ny, nz),
+                                                           _labels_list(keep_labels) if want_t else (),
+                                                           want_gt_occ=want_gt_occ, out_dtype=occ_dtype)
+        return VoxelGrids(None, None, None, None, occ, gt_occ, desc, dropped, flags)
     counts, towers, dropped = _hip.voxel_scatter(batch.pts, batch.labels if want_t else None, batch.offsets, desc,
                                                  (nx, ny, nz), _labels_list(keep_labels) if want_t else (),
                                                  want_towers=want_t)
     density, gt, occ, gt_occ = _hip.voxel_finalize(counts, towers, want_density, want_gt, want_occ, want_gt_occ)
+    if occ is not None and occ_dtype != torch.float32:
+        occ = occ.to(occ_dtype)
+    if gt_occ is not None and occ_dtype != torch.float32:
+        gt_occ = gt_occ.to(occ_dtype)
     return VoxelGrids(counts, towers, density, gt, occ, gt_occ, desc, dropped)
 
 

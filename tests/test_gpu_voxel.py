@@ -21,7 +21,8 @@ def _check_tile(grids, b, xyz, labels, dims, keep):
     assert np.array_equal(desc[:3], g["xyzmin"]) and np.array_equal(desc[3:6], g["xyzmax"])
     edges = np.concatenate(g["segments"])
     assert np.array_equal(desc[6:], edges), "edge table differs from numpy.linspace"
-    assert np.array_equal(grids.counts[b].cpu().numpy(), counts)
+    if grids.counts is not None:
+        assert np.array_equal(grids.counts[b].cpu().numpy(), counts)
     assert int(grids.dropped[b].item()) == 0
     if grids.towers is not None:
         assert np.array_equal(grids.towers[b].cpu().numpy(), towers)
@@ -30,6 +31,9 @@ def _check_tile(grids, b, xyz, labels, dims, keep):
         assert np.array_equal(grids.density[b, 0].cpu().numpy(), dens)
     if grids.occ is not None:
         assert np.array_equal(grids.occ[b, 0].cpu().numpy(), vo.to_full_dense(dens).astype(np.float32))
+    if grids.gt_occ is not None and grids.gt is None:
+        gt = vo.reg_on_voxel(xyz, labels, keep, dims)
+        assert np.array_equal(grids.gt_occ[b, 0].cpu().numpy(), (gt > 0).astype(np.float32))
     if grids.gt is not None:
         gt = vo.reg_on_voxel(xyz, labels, keep, dims)
         assert np.array_equal(grids.gt[b, 0].cpu().numpy(), gt)
@@ -55,8 +59,15 @@ def test_ragged_batch_of_synthetic_tiles(hip_device):
     assert batch.offsets.tolist() == np.concatenate([[0], np.cumsum(sizes)]).tolist()
     g = sna.voxelize_batch(batch, (64, 64, 64), [15, 16], want_density=True, want_gt=True, want_occ=True,
                            want_gt_occ=True)
+    # the occupancy-only (LDS bitmap) path on the same batch, u8 and f32, with and without the tower plane
+    go1 = sna.voxelize_batch(batch, (64, 64, 64), [15, 16], want_occ=True, want_gt_occ=True, occ_dtype=torch.uint8)
+    go2 = sna.voxelize_batch(batch, (64, 64, 64), want_occ=True)
+    assert go1.counts is None and go1.occ.dtype == torch.uint8 and go2.occ.dtype == torch.float32
+    assert go1.flags.sum().item() == 0  # every tile has an empty (z,x) row: no counting fallback
     for b in range(len(sizes)):
         _check_tile(g, b, tiles[b], labels[b], (64, 64, 64), [15, 16])
+        _check_tile(go1, b, tiles[b], labels[b], (64, 64, 64), [15, 16])
+        _check_tile(go2, b, tiles[b], None, (64, 64, 64), None)
         assert int(g.counts[b].sum().item()) == sizes[b]
 
 
@@ -94,6 +105,19 @@ def test_density_column_rule(hip_device):
     counts = g.counts[0].cpu().numpy()
     assert counts[:, :, 2].min() > 0
     assert (g.occ[0, 0].cpu().numpy()[:, :, 2] == (counts[:, :, 2] > counts[:, :, 2].min())).all()
+    # occupancy path: no (z,x) row is empty -> the flag is raised and the gated counting kernels redo the tile
+    labels = np.where(np.arange(len(xyz)) % 3 == 0, 15.0, 2.0)
+    other, _ = synthetic_tile(1, 5000)
+    b2 = sna.PointBatch.from_tiles([xyz, other, xyz], [labels, np.full(5000, 2.0), labels], device=hip_device)
+    for dt in (torch.uint8, torch.float32):
+        g2 = sna.voxelize_batch(b2, (4, 4, 8), [15], want_occ=True, want_gt_occ=True, occ_dtype=dt)
+        assert g2.counts is None
+        for b, (t, l) in enumerate([(xyz, labels), (other, np.full(5000, 2.0)), (xyz, labels)]):
+            _check_tile(g2, b, t, l, (4, 4, 8), [15])
+    g3 = sna.voxelize_batch(b2, (4, 4, 4), [15], want_occ=True, occ_dtype=torch.uint8)
+    assert g3.flags.tolist()[0] == 1 and g3.flags.tolist()[2] == 1
+    _check_tile(g3, 0, xyz, None, (4, 4, 4), None)
+    assert not np.array_equal(g3.occ[0, 0].cpu().numpy(), (counts > 0))  # the rule matters for this tile
 
 
 def test_size_mode_and_reference_signatures(hip_device, golden_dir):
@@ -123,8 +147,11 @@ def test_full_size_c2_batch_properties(hip_device):
     B, N = 32, 100_000
     tiles, labels = zip(*[synthetic_tile(t, N) for t in range(B)])
     batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
-    g1 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True)
-    g2 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True)
+    g1 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True, want_counts=True)
+    g2 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True, want_counts=True)
+    g4 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True, occ_dtype=torch.uint8)
+    assert g4.counts is None and torch.equal(g4.occ.float(), g1.occ) and torch.equal(g4.gt_occ.float(), g1.gt_occ)
+    assert int(g4.flags.sum().item()) == 0 and int(g4.dropped.sum().item()) == 0
     assert torch.equal(g1.counts, g2.counts) and torch.equal(g1.towers, g2.towers) and torch.equal(g1.occ, g2.occ)
     assert g1.counts.sum(dim=(1, 2, 3)).tolist() == [N] * B
     assert int(g1.dropped.sum().item()) == 0
