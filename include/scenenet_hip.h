@@ -37,7 +37,9 @@ typedef enum {
     SN_ERR_NO_DEVICE = -4      /* no gfx950 device / HIP runtime unusable            */
 } sn_status;
 
-typedef enum { SN_F32 = 0, SN_F64 = 1, SN_U8 = 2 } sn_dtype;
+/* SN_OCC8: uint8 grid whose values are all 0 or 1 (binary occupancy, torch.bool) -- lets sn_conv_bank use the
+ * int8 matrix cores.  SN_U8 is a general 0..255 byte grid. */
+typedef enum { SN_F32 = 0, SN_F64 = 1, SN_U8 = 2, SN_OCC8 = 3 } sn_dtype;
 
 /* GENEO kinds, in SceneNet's key order (core/models/SCENE_Net.py:259-272). */
 typedef enum { SN_GENEO_CY = 0, SN_GENEO_CONE = 1, SN_GENEO_NEG = 2 } sn_geneo_kind;
@@ -81,7 +83,9 @@ int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int 
  * x [B,1,Z,X,Y] of x_dtype; bank [G,kz,kx,ky] f32; lambdas [G] f32 = the
  * EFFECTIVE coefficients (last one already 1 - sum(others)), nullable iff out
  * is null.  act (nullable) [B,G,Z,X,Y] and out (nullable) [B,1,Z,X,Y] are of
- * out_dtype (SN_F32 or SN_F64).  fp32 MFMA accumulation.
+ * out_dtype (SN_F32 or SN_F64).  x_dtype SN_F32 / SN_F64 / SN_U8: fp32 MFMA accumulation
+ * (v_mfma_f32_16x16x4_f32).  x_dtype SN_OCC8 (values in {0,1}): weights as 24-bit fixed point in three
+ * int8 digits, exact int32 accumulation on v_mfma_i32_16x16x64_i8, recombined in fp32.
  * G <= 16 per call in this revision.
  * ------------------------------------------------------------------------- */
 int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lambdas,

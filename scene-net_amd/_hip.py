@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libscenenet_hip.so")
 
-SN_F32, SN_F64, SN_U8 = 0, 1, 2
+SN_F32, SN_F64, SN_U8, SN_OCC8 = 0, 1, 2, 3
 SN_GENEO_CY, SN_GENEO_CONE, SN_GENEO_NEG = 0, 1, 2
 SN_P_RADIUS, SN_P_SIGMA, SN_P_APEX, SN_P_CONE_RADIUS, SN_P_CONE_INC, SN_P_NEG_FACTOR = 0, 1, 2, 3, 4, 5
 SN_NPARAM = 8
@@ -86,7 +86,9 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-_DT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8}
+# torch.bool (one byte, 0/1) is the binary-occupancy dtype: sn_conv_bank takes it on the int8 matrix cores
+_DT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_OCC8}
+_DT_OUT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_U8}
 
 
 # --------------------------------------------------------------------------- #
@@ -105,12 +107,12 @@ def geneo_bank(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[
 
 def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tensor], want_act: bool = False,
               want_out: bool = True, out_dtype: Optional[torch.dtype] = None):
-    """x [B,1,Z,X,Y] (f32|f64|u8), bank [G,kz,kx,ky] f32, lambdas [G] f32 (effective) ->
+    """x [B,1,Z,X,Y] (f32|f64|u8|bool), bank [G,kz,kx,ky] f32, lambdas [G] f32 (effective) ->
     (act [B,G,Z,X,Y] | None, out [B,1,Z,X,Y] | None) of out_dtype (sn_conv_bank)."""
     if x.dim() != 5 or x.shape[1] != 1:
         raise HipLibraryError(f"x must be [B,1,Z,X,Y] (got {tuple(x.shape)})")
     if x.dtype not in _DT:
-        raise HipLibraryError(f"x dtype {x.dtype} unsupported (f32, f64, u8)")
+        raise HipLibraryError(f"x dtype {x.dtype} unsupported (f32, f64, u8, bool)")
     B, _, Z, X, Y = x.shape
     G, kz, kx, ky = bank.shape
     if out_dtype is None:
@@ -119,7 +121,7 @@ def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tenso
     out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device) if want_out else None
     rc = load().sn_conv_bank(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
                              _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky,
-                             _ptr(act, None, "act"), _ptr(out, None, "out"), _DT[out_dtype], _stream())
+                             _ptr(act, None, "act"), _ptr(out, None, "out"), _DT_OUT[out_dtype], _stream())
     _check(rc, "sn_conv_bank")
     return act, out
 
@@ -216,7 +218,7 @@ def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[flo
                                    _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
                                    _ptr(offsets, torch.int64, "offsets"), B, _ptr(desc, torch.float64, "desc"),
                                    nx, ny, nz, ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
-                                   _ptr(bits), _ptr(occ), _ptr(gt_occ), _DT[out_dtype], _ptr(flags), _ptr(dropped),
+                                   _ptr(bits), _ptr(occ), _ptr(gt_occ), _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped),
                                    _ptr(counts), _ptr(towers), _ptr(colstats), _stream())
     _check(rc, "sn_voxel_occupancy")
     return occ, gt_occ, flags, dropped

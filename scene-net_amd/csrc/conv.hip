@@ -390,6 +390,11 @@ void set_tile(ConvShape& s, int tz, int tx) {
 
 }  // namespace
 
+namespace sn {
+int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
+                int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream);  // conv_i8.hip
+}
+
 extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,
                             int Y, int G, int kz, int kx, int ky, void* act, void* out, int out_dtype,
                             sn_stream_t stream) {
@@ -403,6 +408,17 @@ extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const
     if (out_dtype != SN_F32 && out_dtype != SN_F64)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank: out_dtype %d", out_dtype);
     if ((size_t)B * Z * X * Y > (size_t)1 << 40) return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_bank: grid too large");
+
+    if (x_dtype == SN_OCC8) {
+        // binary occupancy bytes: int8 matrix cores (exact integer accumulation of 24-bit fixed-point weights)
+        const char* no_i8 = getenv("SN_CONV_NO_I8");
+        if (!(no_i8 && no_i8[0] == '1')) {
+            const int rc = sn::conv_occ_i8((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, act, out,
+                                           out_dtype, sn::as_stream(stream));
+            if (rc <= 0) return rc;
+        }
+        x_dtype = SN_U8;  // shape not served by the int8 kernel: same bytes through the fp32 kernel
+    }
 
     ConvShape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;

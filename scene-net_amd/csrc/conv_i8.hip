@@ -1,0 +1,399 @@
+// K3' -- GENEO bank convolution for BINARY OCCUPANCY input on the int8 matrix cores.
+//
+// Same contraction as csrc/conv.hip (SceneNet.forward, core/models/SCENE_Net.py:322-339) specialised to what
+// the network is actually fed: ToFullDense(Voxelization(points)) is {0,1} (torch_transforms.py:33-34), exact
+// in int8.  The fp32 GENEO weights are turned into 24-bit fixed point per kernel,
+//     Q[g][t] = rint(W[g][t] * 2^F_g),  2^(22-F_g) >= max_t |W[g][t]|   (|Q| <= 2^22)
+// and split into three balanced base-256 digits Q = d0 + 256 d1 + 65536 d2, d_i in [-128, 127].  Three
+// v_mfma_i32_16x16x64_i8 per 64 taps accumulate S_i = sum_t d_i[g][t] x[v+t] EXACTLY in int32 (order
+// independent, bit-reproducible); the epilogue recombines (S2*65536 + S1*256 + S0) * 2^-F_g in fp32.
+// Error vs the fp64 reference: the weight quantisation only, <= 2^-23 * 2^ceil(log2 max|W_g|) per tap
+// (same order as an fp32 fmaf chain), plus one fp32 rounding of the sum.
+//
+// GEMM view per 16-voxel strip along y: M = 16 kernels (A = digit bytes), N = 16 voxels (B = occupancy
+// bytes), K = 64 "slots" per MFMA.  A lane (q = l>>4, n = l&15) supplies 16 bytes = 4 dwords per MFMA; each
+// dword is a CHUNK = 4 consecutive dy taps of one (dz,dx) kernel row at voxel n.  ky taps are padded to
+// C = ceil(ky/4) chunks (zero digits), so K is R*C*4 slots, R = kz*kx  (9^3: 972 slots, 16 MFMA steps x 3
+// digits = 48 MFMAs of 16 cycles per 16x16 outputs, against 184 fp32 MFMAs of 32 cycles).
+//
+// A chunk starts at an arbitrary byte (voxel y + 4c), but ds_read_b32 wants 4-byte alignment: the halo tile
+// is kept in LDS as FOUR copies, copy k shifted by k bytes, so lane n reads copy (n+delta)&3 at the aligned
+// address below its start.  Both operands use the same slot->tap table, so only the row/column lane maps of
+// the MFMA matter (A row = l&15, B col = l&15, D row = 4*(l>>4)+r, col = l&15), not the k order inside it.
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int TY = 64;        // y extent of a workgroup tile
+constexpr int NV = 8;         // accumulator tiles per wave round: 2 x-rows x 4 y-strips
+constexpr int YPB = 96;       // halo row stride in bytes (24 dwords: rows 2 apart differ by 16 banks)
+constexpr int kMaxC = 6;      // chunks per kernel row: ky <= 24
+constexpr int kCopyPad = 16;  // copy stride = tile bytes + 16: the 4 copies start 4 banks apart
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kTablePad = 2;  // all-zero MFMA steps the software pipeline may prefetch
+
+struct Shape {
+    int B, Z, X, Y, G;
+    int kz, kx, ky;
+    int TZ, TX, nzt, nxt, nyt, ntiles;
+    int C, R, KS;   // chunks per row, kernel rows, MFMA steps (even)
+    int PYA, delta; // halo origin = y0 - PYA (PYA = roundup(py, 4)), delta = PYA - py
+    int CB;         // bytes between the shifted copies
+};
+
+struct TileCoord {
+    int b, z0, x0, y0;
+};
+
+__device__ __forceinline__ TileCoord tile_coord(const Shape& s, int tile) {
+    TileCoord c;
+    c.y0 = (tile % s.nyt) * TY; tile /= s.nyt;
+    c.x0 = (tile % s.nxt) * s.TX; tile /= s.nxt;
+    c.z0 = (tile % s.nzt) * s.TZ; tile /= s.nzt;
+    c.b = tile;
+    return c;
+}
+
+__device__ uint32_t g_zero_word[4] = {0u, 0u, 0u, 0u};
+
+// slot (step s, lane group q, dword j) -> chunk list index.  The list is c-major (all rows of chunk column
+// 0, then column 1, ...), and the two lane groups that share an LDS cycle (q = 0,1 and q = 2,3) are placed 2
+// list entries = 2 halo rows = 48 dwords = 16 banks apart.
+__device__ __forceinline__ int slot_index(int s, int q, int j) {
+    const int perm = ((q & 1) << 1) | (q >> 1);  // 0,2,1,3
+    return s * 16 + j * 4 + perm;
+}
+
+// halo tile: copies[k][r][i] (bytes), copy k = tile shifted by k bytes.  Global rows are read as aligned
+// dwords (Y % 4 == 0, origin y0 - PYA is a multiple of 4): out-of-grid dwords come from a zero word.
+__device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_t* __restrict__ x, const Shape& s,
+                                          const TileCoord& c, int tid, int XP, int rows) {
+    constexpr int DW = YPB / 4;
+    const int total = rows * DW;
+    constexpr int kBatch = 4;
+    for (int base = tid; base < total; base += kThreads * kBatch) {
+        uint32_t lo[kBatch], hi[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int idx = base + u * kThreads;
+            const int r = idx / DW, i = idx - r * DW;
+            const int zz = r / XP, xx = r - zz * XP;
+            const int gz = c.z0 - (s.kz - 1) / 2 + zz, gx = c.x0 - (s.kx - 1) / 2 + xx;
+            const int gy = c.y0 - s.PYA + 4 * i;
+            const bool okr = (idx < total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X);
+            const uint8_t* row = x + (((size_t)c.b * s.Z + gz) * s.X + gx) * s.Y;
+            const uint32_t* p0 = (okr && gy >= 0 && gy < s.Y) ? reinterpret_cast<const uint32_t*>(row + gy)
+                                                             : g_zero_word;
+            const uint32_t* p1 = (okr && gy + 4 >= 0 && gy + 4 < s.Y) ? reinterpret_cast<const uint32_t*>(row + gy + 4)
+                                                                     : g_zero_word;
+            lo[u] = *p0;
+            hi[u] = *p1;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int idx = base + u * kThreads;
+            if (idx < total) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(xs) + idx;  // dword idx of copy 0
+                d[0] = lo[u];
+                d[(s.CB >> 2)] = __builtin_amdgcn_alignbyte(hi[u], lo[u], 1);
+                d[2 * (s.CB >> 2)] = __builtin_amdgcn_alignbyte(hi[u], lo[u], 2);
+                d[3 * (s.CB >> 2)] = __builtin_amdgcn_alignbyte(hi[u], lo[u], 3);
+            }
+        }
+    }
+}
+
+template <typename OT>
+__global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __restrict__ x,
+                                                               const float* __restrict__ bank,
+                                                               const float* __restrict__ lambdas, Shape s,
+                                                               OT* __restrict__ act, OT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+
+    const int ZP = s.TZ + s.kz - 1, XP = s.TX + s.kx - 1;
+    const int rows = ZP * XP;
+    const int ntaps = s.kz * s.kx * s.ky;
+    const int KT = s.KS + kTablePad;
+    // LDS carve-up
+    uint4* Wd = reinterpret_cast<uint4*>(lds);                            // [KT][3][64] x 16 B
+    int4* coff = reinterpret_cast<int4*>(lds + (size_t)KT * 3 * 64 * 16); // [KT][4] x 16 B
+    float* scale = reinterpret_cast<float*>(coff + KT * 4);               // [16]   2^-F_g
+    int* shiftF = reinterpret_cast<int*>(scale + 16);                     // [16]   F_g
+    uint8_t* xs = reinterpret_cast<uint8_t*>(shiftF + 16);                // 4 copies x CB bytes
+
+    // ---- once per workgroup: per-kernel fixed-point scale
+    for (int g = wave; g < 16; g += kWaves) {
+        float m = 0.0f;
+        if (g < s.G)
+            for (int t = lane; t < ntaps; t += 64) m = fmaxf(m, fabsf(bank[(size_t)g * ntaps + t]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            int e = 0;
+            if (m > 0.0f) (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)  ->  m <= 2^e
+            const int F = 22 - e;
+            shiftF[g] = F;
+            scale[g] = ldexpf(1.0f, -F);
+        }
+    }
+    __syncthreads();
+    // ---- digit table Wd[s][d][l] (16 bytes: slot (q, p)) and chunk offset table coff[s][q] (4 dwords j)
+    const int nchunks = s.R * s.C;
+    for (int i = tid; i < KT * 3 * 64; i += kThreads) {
+        const int l = i & 63, d = (i >> 6) % 3, st = i / 192;
+        const int g = l & 15, qq = l >> 4;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (g < s.G && st < s.KS) {
+            const int F = shiftF[g];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int li = slot_index(st, qq, j);
+                if (li < nchunks) {
+                    const int c = li / s.R, rho = li - c * s.R;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int dy = 4 * c + b;
+                        if (dy < s.ky) {
+                            const float wv = bank[(size_t)g * ntaps + rho * s.ky + dy];
+                            int Q = __float2int_rn(ldexpf(wv, F));
+                            const int d0 = ((Q + 128) & 255) - 128;
+                            Q = (Q - d0) >> 8;
+                            const int d1 = ((Q + 128) & 255) - 128;
+                            const int d2 = (Q - d1) >> 8;
+                            const int dig = (d == 0) ? d0 : (d == 1) ? d1 : d2;
+                            w[j] |= (uint32_t)(dig & 255) << (8 * b);
+                        }
+                    }
+                }
+            }
+        }
+        Wd[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    for (int i = tid; i < KT * 4; i += kThreads) {
+        const int qq = i & 3, st = i >> 2;
+        int o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int li = slot_index(st, qq, j);
+            if (st < s.KS && li < nchunks) {
+                const int c = li / s.R, rho = li - c * s.R;
+                const int dz = rho / s.kx, dx = rho - dz * s.kx;
+                o[j] = (dz * XP + dx) * YPB + 4 * c;
+            }
+        }
+        coff[i] = make_int4(o[0], o[1], o[2], o[3]);
+    }
+
+    float lam[4] = {0.f, 0.f, 0.f, 0.f}, sc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int g = 4 * q + r;
+        sc[r] = scale[g];
+        if (out) lam[r] = (g < s.G) ? lambdas[g] : 0.0f;
+    }
+
+    const int half_tx = s.TX >> 1;
+    const int nrounds = s.TZ * half_tx;
+    const size_t V = (size_t)s.Z * s.X * s.Y;
+    const int nd = n + s.delta;
+    const int lanebase = (nd & 3) * s.CB + (nd & ~3);
+
+    int tile = blockIdx.x;
+    if (tile >= s.ntiles) return;
+    halo_fill(xs, x, s, tile_coord(s, tile), tid, XP, rows);
+    __syncthreads();
+
+    for (; tile < s.ntiles; tile += gridDim.x) {
+        const TileCoord c = tile_coord(s, tile);
+        for (int round = wave; round < nrounds; round += kWaves) {
+            const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
+            const uint8_t* xb = xs + lanebase + (lz * XP + lx) * YPB;
+
+            i32x4 acc[3][NV];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[d][v] = i32x4{0, 0, 0, 0};
+
+            auto gather = [&](const int4& co, i32x4 (&xv)[NV]) {
+                const uint8_t* p0 = xb + co.x;
+                const uint8_t* p1 = xb + co.y;
+                const uint8_t* p2 = xb + co.z;
+                const uint8_t* p3 = xb + co.w;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int to = (v >> 2) * YPB + (v & 3) * 16;
+                    xv[v] = i32x4{*reinterpret_cast<const int*>(p0 + to), *reinterpret_cast<const int*>(p1 + to),
+                                  *reinterpret_cast<const int*>(p2 + to), *reinterpret_cast<const int*>(p3 + to)};
+                }
+            };
+            auto load_w = [&](int st, i32x4 (&w)[3]) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint4 u = Wd[(st * 3 + d) * 64 + lane];
+                    w[d] = i32x4{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
+                }
+            };
+            auto mma = [&](const i32x4 (&w)[3], const i32x4 (&xv)[NV]) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv[v], acc[d][v], 0, 0, 0);
+            };
+
+            // software pipeline, ping-pong by 2 (KS is even; the tables carry kTablePad zero steps)
+            i32x4 wa[3], wb[3], xa[NV], xb2[NV];
+            int4 ca = coff[1 * 4 + q], cb;
+            load_w(0, wa);
+            gather(coff[q], xa);
+            for (int st = 0; st < s.KS; st += 2) {
+                load_w(st + 1, wb);
+                cb = coff[(st + 2) * 4 + q];
+                gather(ca, xb2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wa, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(st + 2, wa);
+                ca = coff[(st + 3) * 4 + q];
+                gather(cb, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wb, xb2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // ---- epilogue: recombine the digits, then the same head as the fp32 kernel
+            const int gz = c.z0 + lz;
+            if (gz >= s.Z) continue;
+            float val[NV][4];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float f = (float)acc[2][v][r] * 65536.0f;
+                    f = fmaf((float)acc[1][v][r], 256.0f, f);
+                    f += (float)acc[0][v][r];
+                    val[v][r] = f * sc[r];
+                }
+            if (act) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int gx = c.x0 + lx + (v >> 2), gy = c.y0 + (v & 3) * 16 + n;
+                    if (gx < s.X && gy < s.Y) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g = 4 * q + r;
+                            if (g < s.G)
+                                act[((size_t)c.b * s.G + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy] =
+                                    (OT)val[v][r];
+                        }
+                    }
+                }
+            }
+            if (out) {
+                float sums[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float p = lam[0] * val[v][0];
+                    p = fmaf(lam[1], val[v][1], p);
+                    p = fmaf(lam[2], val[v][2], p);
+                    p = fmaf(lam[3], val[v][3], p);
+                    p += __shfl_xor(p, 16, 64);
+                    p += __shfl_xor(p, 32, 64);
+                    sums[v] = p;
+                }
+#pragma unroll
+                for (int xr = 0; xr < 2; ++xr) {
+                    const float a0 = sums[4 * xr + 0], a1 = sums[4 * xr + 1], a2 = sums[4 * xr + 2],
+                                a3 = sums[4 * xr + 3];
+                    const float sv = (q == 0) ? a0 : (q == 1) ? a1 : (q == 2) ? a2 : a3;
+                    const int gx = c.x0 + lx + xr, gy = c.y0 + q * 16 + n;
+                    if (gx < s.X && gy < s.Y)
+                        out[(size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy] = (OT)fmaxf(tanhf(sv), 0.0f);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading the halo tile
+        const int next = tile + gridDim.x;
+        if (next < s.ntiles) halo_fill(xs, x, s, tile_coord(s, next), tid, XP, rows);
+        __syncthreads();
+    }
+}
+
+size_t lds_bytes(const Shape& s) {
+    const size_t KT = s.KS + kTablePad;
+    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + 4 * (size_t)s.CB;
+}
+
+int num_cus() {
+    static thread_local int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    cached = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    return cached;
+}
+
+}  // namespace
+
+namespace sn {
+
+// returns SN_OK, an error, or 1 when this shape is not served by the int8 kernel (caller falls back to fp32)
+int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
+                int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream) {
+    if (Y % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 3) != 0 || G > 16) return 1;
+    Shape s;
+    s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
+    s.C = (ky + 3) / 4;
+    if (s.C > kMaxC) return 1;
+    s.R = kz * kx;
+    s.KS = (((s.R * s.C + 15) / 16) + 1) & ~1;
+    const int py = (ky - 1) / 2;
+    s.PYA = (py + 3) & ~3;
+    s.delta = s.PYA - py;
+    if (s.delta + 15 + 48 + 4 * s.C + 3 > YPB) return 1;
+    s.nyt = (Y + TY - 1) / TY;
+    const int cus = num_cus();
+    static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
+    bool found = false;
+    for (const auto& c : cand) {
+        s.TZ = c[0]; s.TX = c[1];
+        s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
+        s.ntiles = B * s.nzt * s.nxt * s.nyt;
+        s.CB = (s.TZ + kz - 1) * (s.TX + kx - 1) * YPB + kCopyPad;
+        if (lds_bytes(s) > (size_t)kMaxLds) continue;
+        found = true;
+        if (s.ntiles >= 4 * cus) break;
+    }
+    if (!found) return 1;
+    int grid = cus < s.ntiles ? cus : s.ntiles;
+    const size_t lds = lds_bytes(s);
+    if (out_dtype == SN_F32) {
+        auto kern = conv_occ_i8_kernel<float>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess)
+            return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (float*)act,
+                           (float*)out);
+    } else {
+        auto kern = conv_occ_i8_kernel<double>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess)
+            return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (double*)act,
+                           (double*)out);
+    }
+    return check_launch("sn_conv_bank(i8)");
+}
+
+}  // namespace sn

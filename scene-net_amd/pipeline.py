@@ -59,9 +59,9 @@ class ScenePipeline:
         self.keep_labels = keep_labels
 
     def voxelize(self, batch: PointBatch, want_gt: bool = False) -> VoxelGrids:
-        # u8 occupancy: 1 byte/voxel between K1 and K3 instead of 4
+        # binary occupancy as torch.bool: 1 byte/voxel between K1 and K3, and K3 runs on the int8 matrix cores
         return voxelize_batch(batch, self.voxelgrid_dims, self.keep_labels, want_occ=True, want_gt_occ=want_gt,
-                              occ_dtype=torch.uint8)
+                              occ_dtype=torch.bool)
 
     def __call__(self, batch: PointBatch, want_gt: bool = False):
         grids = self.voxelize(batch, want_gt)

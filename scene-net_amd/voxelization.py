@@ -112,7 +112,7 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
                                                  want_towers=want_t)
     density, gt, occ, gt_occ = _hip.voxel_finalize(counts, towers, want_density, want_gt, want_occ, want_gt_occ)
     if occ is not None and occ_dtype != torch.float32:
-        occ = occ.to(occ_dtype)
+        occ = occ.to(occ_dtype)  # values are exactly 0 / 1
     if gt_occ is not None and occ_dtype != torch.float32:
         gt_occ = gt_occ.to(occ_dtype)
     return VoxelGrids(counts, towers, density, gt, occ, gt_occ, desc, dropped)

@@ -170,3 +170,81 @@ def test_128_cubed_tile_properties(hip_device):
     assert torch.equal(act[0, :, 123:, 123:, 123:], bank.flip(1, 2, 3)[:, :5, :5, :5])
     assert act.abs().sum().item() == pytest.approx(
         (bank.abs().sum() + bank[:, :5, :5, :5].abs().sum() + bank[:, 4:, 4:, 4:].abs().sum()).item(), rel=1e-5)
+
+
+# ------------------------------------------------------------------ binary occupancy on the int8 matrix cores
+@pytest.mark.parametrize("tag", ["ckpt955", "c1_999", "g16_999", "even_656"])
+def test_golden_forward_occupancy_i8(hip_device, golden_dir, tag):
+    """The golden inputs are binary: as torch.bool they take the int8 (24-bit fixed-point weight) kernel."""
+    F = np.load(os.path.join(golden_dir, "geneo_forward.npz"))
+    names = [str(n) for n in F[f"{tag}/names"]]
+    bank = torch.from_numpy(F[f"{tag}/bank"][:, 0]).float().to(hip_device).contiguous()
+    lam = go.effective_lambdas(F[f"{tag}/lambdas"], int(F[f"{tag}/last"]), names).to(hip_device)
+    x = torch.from_numpy(F[f"{tag}/x"]).to(torch.bool).to(hip_device)
+    act, out = _hip.conv_bank(x, bank, lam, want_act=True, want_out=True, out_dtype=torch.float64)
+    e_act = (act.cpu() - torch.from_numpy(F[f"{tag}/conv"])).abs().max().item()
+    e_out = (out.cpu() - torch.from_numpy(F[f"{tag}/out"])).abs().max().item()
+    print(tag, "i8 act err", e_act, "out err", e_out)
+    assert e_act < TOL and e_out < TOL
+
+
+@pytest.mark.parametrize("shape,ks,G", [
+    ((2, 1, 16, 16, 16), (9, 9, 9), 16),
+    ((1, 1, 13, 9, 72), (9, 9, 9), 16),      # ragged z/x, y > 64
+    ((3, 1, 8, 10, 36), (9, 5, 5), 3),
+    ((1, 1, 20, 6, 132), (6, 5, 6), 5),      # even dims
+    ((2, 1, 5, 4, 4), (3, 3, 3), 1),
+    ((1, 1, 9, 9, 12), (1, 1, 1), 2),
+    ((1, 1, 12, 12, 12), (5, 7, 3), 7),
+    ((1, 1, 7, 7, 40), (3, 3, 24), 4),       # widest ky the int8 kernel takes
+    ((1, 1, 7, 7, 40), (3, 3, 25), 4),       # ky = 25: served by the fp32 kernel (same answer)
+    ((1, 1, 6, 6, 30), (3, 3, 3), 4),        # Y % 4 != 0: served by the fp32 kernel
+])
+def test_occupancy_i8_against_oracle(hip_device, shape, ks, G):
+    torch.manual_seed(hash((shape, ks, G)) % 2**31)
+    occ = torch.rand(shape) < 0.3
+    bank = _rand_bank(G, ks, 5, "cpu") * torch.logspace(-3, 1, G).view(G, 1, 1, 1)  # kernels of very different scale
+    lam = (torch.rand(G) - 0.3) / G
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    act, out = _hip.conv_bank(occ.to(hip_device), bank.to(hip_device).contiguous(), lam.to(hip_device),
+                              want_act=True, want_out=True)
+    assert act.dtype == torch.float32
+    # per kernel: error relative to that kernel's own scale (fixed point is per kernel)
+    for g in range(G):
+        scale = max(1.0, ref_act[:, g].abs().max().item()) * max(1.0, 0.0)
+        wmax = bank[g].abs().max().item()
+        err = (act[:, g].cpu().double() - ref_act[:, g]).abs().max().item()
+        assert err < TOL * max(wmax, 1e-30) * 10 and err < TOL * scale, (g, err, wmax)
+    assert (out.cpu().double() - ref_out).abs().max().item() < TOL
+    # and the fp32 kernel on the same bytes agrees
+    act32, out32 = _hip.conv_bank(occ.to(torch.uint8).to(hip_device), bank.to(hip_device).contiguous(),
+                                  lam.to(hip_device), want_act=True, want_out=True)
+    assert (act32 - act).abs().max().item() < TOL and (out32 - out).abs().max().item() < TOL
+
+
+def test_occupancy_i8_is_exact_for_exactly_representable_weights(hip_device):
+    """Integer accumulation: with weights that are multiples of 2^-10 the result is exact, whatever the order."""
+    torch.manual_seed(9)
+    occ = torch.rand(4, 1, 32, 32, 64, device=hip_device) < 0.2
+    bank = (torch.randint(-1024, 1025, (16, 9, 9, 9)).float() / 1024).to(hip_device).contiguous()
+    act, _ = _hip.conv_bank(occ, bank, None, want_act=True, want_out=False)
+    ref = go.conv_bank(occ.cpu().double(), bank.cpu().double().unsqueeze(1))
+    assert torch.equal(act.cpu().double(), ref)
+    act2, _ = _hip.conv_bank(occ, bank, None, want_act=True, want_out=False)
+    assert torch.equal(act, act2)
+
+
+def test_full_size_c2_tile_occupancy_i8(hip_device):
+    from scene_net_amd.synthetic import synthetic_bank_spec
+    specs, names, lambdas, last = synthetic_bank_spec()
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.random((2, 1, 64, 64, 64)) < 0.035)
+    ref_out, ref_act = go.scenenet_forward(x.double(), specs, (9, 9, 9), lambdas, last, return_bank=True, names=names)
+    bank = go.geneo_bank(specs, (9, 9, 9))[:, 0].float().to(hip_device).contiguous()
+    lam_eff = go.effective_lambdas(lambdas, last, names).to(hip_device)
+    act, out = _hip.conv_bank(x.to(hip_device), bank, lam_eff, want_act=True, want_out=True)
+    e_act = (act.cpu().double() - ref_act).abs().max().item()
+    e_out = (out.cpu().double() - ref_out).abs().max().item()
+    print("C2 tiles (i8): act err", e_act, "out err", e_out)
+    assert e_act < TOL and e_out < TOL
