@@ -111,6 +111,12 @@ int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lam
 /* Per-tile bounding box: bbox [B,6] f64 = (min x,y,z, max x,y,z). */
 int sn_voxel_bbox(const double* pts, const int64_t* offsets, int B, double* bbox, sn_stream_t stream);
 
+/* sn_voxel_bbox + sn_voxel_desc in two launches (no atomics, nothing to initialise) for the batch pipeline:
+ * partial_ws is scratch [B, SN_BBOX_PARTS, 6] f64; bbox (nullable) receives the raw boxes. */
+#define SN_BBOX_PARTS 32
+int sn_voxel_prepare(const double* pts, const int64_t* offsets, int B, int nx, int ny, int nz, int regular,
+                     double* partial_ws, double* bbox, double* desc, sn_stream_t stream);
+
 /* Grid descriptor from a bounding box, n_x/n_y/n_z mode
  * (add_structure("voxelgrid", n_x, n_y, n_z), pcd_processing.py:362-363):
  * regular != 0 pads the box to a cube (pyntcloud regular_bounding_box=True);
@@ -151,18 +157,18 @@ int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_counts, int B,
  * (64^3 with or without gt_occ); otherwise SN_ERR_UNSUPPORTED -> use sn_voxel_scatter + sn_voxel_finalize.
  *   bits_ws     scratch, SN_OCC_WS_WORDS(B, nx*ny*nz, planes) uint32 (planes = 2 with gt_occ, else 1)
  *   flags       (nullable) [B] i32 out: 1 = the tile could not be proven free of a fully occupied y column
- *               (where ToFullDense(density) != (count > 0)); such tiles are recomputed exactly by the
- *               counting kernels when counts_ws / colstats_ws (and towers_ws with gt_occ) are given:
- *               counts_ws, towers_ws [B,nz,nx,ny] i32, colstats_ws [B,2,ny] i32 (all nullable).
+ *               (where ToFullDense(density) != (count > 0)); such tiles are recomputed exactly (counts by
+ *               global atomics, column minima) by one gated launch when counts_ws (and towers_ws with
+ *               gt_occ) is given: counts_ws, towers_ws [B,nz,nx,ny] i32 scratch (nullable).
  *   dropped     (nullable) [B] i32: points outside the edge table. */
 #define SN_OCC_PARTS 8
-#define SN_OCC_WS_WORDS(B, V, planes) ((size_t)(B) * SN_OCC_PARTS * (planes) * ((V) / 32))
+#define SN_OCC_WS_WORDS(B, V, planes) ((size_t)(B) * SN_OCC_PARTS * ((planes) * ((V) / 32) + 1))
 int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* offsets, int B,
                        const double* desc, int nx, int ny, int nz,
                        const double* keep_labels_host, int n_keep,
                        uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
                        int32_t* flags, int32_t* dropped,
-                       int32_t* counts_ws, int32_t* towers_ws, int32_t* colstats_ws, sn_stream_t stream);
+                       int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -33,9 +33,11 @@ SYMBOLS = {
     "sn_voxel_desc_from_bounds": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "sn_voxel_scatter": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "sn_voxel_finalize": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
 }
 SN_OCC_PARTS = 8
+SN_BBOX_PARTS = 32
 OCC_MAX_WORDS = 16 * 1024
 
 
@@ -139,6 +141,21 @@ def voxel_bbox(pts: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     return bbox
 
 
+def voxel_prepare(pts: torch.Tensor, offsets: torch.Tensor, n_xyz: Sequence[int], regular: bool = True,
+                  want_bbox: bool = False):
+    """bbox + cube + linspace edge tables in two launches (sn_voxel_prepare): returns (desc, bbox | None)."""
+    B = offsets.numel() - 1
+    nx, ny, nz = (int(v) for v in n_xyz)
+    dev = pts.device
+    partial = torch.empty((B, SN_BBOX_PARTS, 6), dtype=torch.float64, device=dev)
+    desc = torch.empty((B, desc_len(nx, ny, nz)), dtype=torch.float64, device=dev)
+    bbox = torch.empty((B, 6), dtype=torch.float64, device=dev) if want_bbox else None
+    rc = load().sn_voxel_prepare(_ptr(pts, torch.float64, "pts"), _ptr(offsets, torch.int64, "offsets"), B, nx, ny, nz,
+                                 int(regular), _ptr(partial), _ptr(bbox), _ptr(desc), _stream())
+    _check(rc, "sn_voxel_prepare")
+    return desc, bbox
+
+
 def voxel_desc(bbox: torch.Tensor, n_xyz: Sequence[int], regular: bool = True, from_bounds: bool = False):
     B = bbox.shape[0]
     nx, ny, nz = (int(v) for v in n_xyz)
@@ -203,22 +220,21 @@ def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[flo
     V = nx * ny * nz
     dev = pts.device
     planes = 2 if want_gt_occ else 1
-    bits = torch.empty((B * SN_OCC_PARTS * planes * (V // 32),), dtype=torch.int32, device=dev)
+    bits = torch.empty((B * SN_OCC_PARTS * (planes * (V // 32) + 1),), dtype=torch.int32, device=dev)
     occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev)
     gt_occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev) if want_gt_occ else None
     flags = torch.empty((B,), dtype=torch.int32, device=dev)
     dropped = torch.empty((B,), dtype=torch.int32, device=dev)
-    counts = towers = colstats = None
-    if exact_fallback:  # scratch for tiles whose flag is raised (gated kernels: untouched otherwise)
+    counts = towers = None
+    if exact_fallback:  # scratch for tiles whose flag is raised (gated launch: untouched otherwise)
         counts = torch.empty((B, V), dtype=torch.int32, device=dev)
         towers = torch.empty((B, V), dtype=torch.int32, device=dev) if want_gt_occ else None
-        colstats = torch.empty((B, 2, ny), dtype=torch.int32, device=dev)
     keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
     rc = load().sn_voxel_occupancy(_ptr(pts, torch.float64, "pts"),
                                    _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
                                    _ptr(offsets, torch.int64, "offsets"), B, _ptr(desc, torch.float64, "desc"),
                                    nx, ny, nz, ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
                                    _ptr(bits), _ptr(occ), _ptr(gt_occ), _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped),
-                                   _ptr(counts), _ptr(towers), _ptr(colstats), _stream())
+                                   _ptr(counts), _ptr(towers), _stream())
     _check(rc, "sn_voxel_occupancy")
     return occ, gt_occ, flags, dropped

@@ -44,6 +44,8 @@ struct Shape {
     int C, R, KS;   // chunks per row, kernel rows, MFMA steps (even)
     int PYA, delta; // halo origin = y0 - PYA (PYA = roundup(py, 4)), delta = PYA - py
     int CB;         // bytes between the shifted copies
+    int stagger;    // s_sleep units (64 clk) by which waves 4-7 start each tile late
+    int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier
 };
 
 struct TileCoord {
@@ -75,7 +77,7 @@ __device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_
                                           const TileCoord& c, int tid, int XP, int rows) {
     constexpr int DW = YPB / 4;
     const int total = rows * DW;
-    constexpr int kBatch = 4;
+    constexpr int kBatch = 11;  // (16*16 rows x 24 dwords) / 512 threads = 10.5: one batch, one latency
     for (int base = tid; base < total; base += kThreads * kBatch) {
         uint32_t lo[kBatch], hi[kBatch];
 #pragma unroll
@@ -129,11 +131,31 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     int* shiftF = reinterpret_cast<int*>(scale + 16);                     // [16]   F_g
     uint8_t* xs = reinterpret_cast<uint8_t*>(shiftF + 16);                // 4 copies x CB bytes
 
-    // ---- once per workgroup: per-kernel fixed-point scale
+    // ---- once per workgroup: the fp32 bank is staged in LDS (in the still unused halo area; coalesced,
+    // batched loads), then the per-kernel fixed-point scale and the digit table are computed out of LDS.
+    float* bank_s = reinterpret_cast<float*>(xs);  // [G][ntaps]
+    {
+        const int nb = s.G * ntaps;
+        constexpr int kB = 8;
+        for (int base = tid; base < nb; base += kThreads * kB) {
+            float v[kB];
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const int i = base + u * kThreads;
+                v[u] = bank[i < nb ? i : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const int i = base + u * kThreads;
+                if (i < nb) bank_s[i] = v[u];
+            }
+        }
+    }
+    __syncthreads();
     for (int g = wave; g < 16; g += kWaves) {
         float m = 0.0f;
         if (g < s.G)
-            for (int t = lane; t < ntaps; t += 64) m = fmaxf(m, fabsf(bank[(size_t)g * ntaps + t]));
+            for (int t = lane; t < ntaps; t += 64) m = fmaxf(m, fabsf(bank_s[g * ntaps + t]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if (lane == 0) {
@@ -162,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     for (int b = 0; b < 4; ++b) {
                         const int dy = 4 * c + b;
                         if (dy < s.ky) {
-                            const float wv = bank[(size_t)g * ntaps + rho * s.ky + dy];
+                            const float wv = bank_s[g * ntaps + rho * s.ky + dy];
                             int Q = __float2int_rn(ldexpf(wv, F));
                             const int d0 = ((Q + 128) & 255) - 128;
                             Q = (Q - d0) >> 8;
@@ -208,11 +230,17 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
 
     int tile = blockIdx.x;
     if (tile >= s.ntiles) return;
+    __syncthreads();  // the staged bank (aliasing the halo area) is dead from here on
     halo_fill(xs, x, s, tile_coord(s, tile), tid, XP, rows);
     __syncthreads();
 
     for (; tile < s.ntiles; tile += gridDim.x) {
         const TileCoord c = tile_coord(s, tile);
+        // Waves w and w+4 share a SIMD and run the same program from the same barrier: left alone they stay in
+        // lockstep (both in the MFMA loop, then both in the VALU epilogue, matrix pipe idle).  Starting the
+        // second half late by about one epilogue keeps one wave's epilogue under its partner's MFMAs.
+        if (__builtin_amdgcn_readfirstlane(wave) >= kWaves / 2)
+            for (int i = 0; i < s.stagger; ++i) __builtin_amdgcn_s_sleep(8);
         for (int round = wave; round < nrounds; round += kWaves) {
             const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
             const uint8_t* xb = xs + lanebase + (lz * XP + lx) * YPB;
@@ -255,24 +283,40 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             int4 ca = coff[1 * 4 + q], cb;
             load_w(0, wa);
             gather(coff[q], xa);
+            // Each half step: 20 LDS reads for the NEXT step and 24 MFMAs of the CURRENT one.  Issued as two
+            // blocks the LDS queue fills while the matrix pipe drains and vice versa; the group barriers below
+            // make the scheduler interleave them (3 MFMAs, then up to 3 LDS reads, eight times).
+#define SN_I8_INTERLEAVE()                                                  \
+    _Pragma("unroll") for (int gi = 0; gi < 8; ++gi) {                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                  \
+    }
             for (int st = 0; st < s.KS; st += 2) {
                 load_w(st + 1, wb);
                 cb = coff[(st + 2) * 4 + q];
                 gather(ca, xb2);
-                __builtin_amdgcn_sched_barrier(0);
                 mma(wa, xa);
+                SN_I8_INTERLEAVE();
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(st + 2, wa);
                 ca = coff[(st + 3) * 4 + q];
                 gather(cb, xa);
-                __builtin_amdgcn_sched_barrier(0);
                 mma(wb, xb2);
+                SN_I8_INTERLEAVE();
                 __builtin_amdgcn_sched_barrier(0);
             }
+#undef SN_I8_INTERLEAVE
 
             // ---- epilogue: recombine the digits, then the same head as the fp32 kernel
             const int gz = c.z0 + lz;
             if (gz >= s.Z) continue;
+            if (s.dbg & 1) {  // timing experiment: keep the accumulators live, skip the epilogue
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(acc[d][v]));
+                continue;
+            }
             float val[NV][4];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -321,16 +365,18 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 }
             }
         }
-        __syncthreads();  // every wave is done reading the halo tile
+        if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile
         const int next = tile + gridDim.x;
-        if (next < s.ntiles) halo_fill(xs, x, s, tile_coord(s, next), tid, XP, rows);
-        __syncthreads();
+        if (next < s.ntiles && !(s.dbg & 2)) halo_fill(xs, x, s, tile_coord(s, next), tid, XP, rows);
+        if (!(s.dbg & 4)) __syncthreads();
     }
 }
 
 size_t lds_bytes(const Shape& s) {
     const size_t KT = s.KS + kTablePad;
-    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + 4 * (size_t)s.CB;
+    const size_t halo = 4 * (size_t)s.CB;
+    const size_t staged_bank = (size_t)s.G * s.kz * s.kx * s.ky * sizeof(float);  // aliases the halo area
+    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
 }
 
 int num_cus() {
@@ -365,6 +411,10 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     s.delta = s.PYA - py;
     if (s.delta + 15 + 48 + 4 * s.C + 3 > YPB) return 1;
     s.nyt = (Y + TY - 1) / TY;
+    const char* st = getenv("SN_CONV_I8_STAGGER");
+    s.stagger = st ? atoi(st) : 0;  // x 8 x 64 clk
+    const char* dbg = getenv("SN_CONV_I8_DBG");
+    s.dbg = dbg ? atoi(dbg) : 0;
     const int cus = num_cus();
     static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
     bool found = false;

@@ -146,20 +146,79 @@ __global__ void bbox_decode_kernel(unsigned long long* enc, const int64_t* __res
     reinterpret_cast<double*>(enc)[i] = v;
 }
 
+// Fused form for the batch pipeline: per-workgroup partial boxes (no atomics, nothing to initialise) ...
+template <bool kAligned>
+__global__ __launch_bounds__(kThreads) void bbox_partial_kernel(const double* __restrict__ pts,
+                                                                const int64_t* __restrict__ offsets,
+                                                                double* __restrict__ partial) {
+    __shared__ double red[kThreads / 64][6];
+    const int b = blockIdx.y;
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kThreads + threadIdx.x,
+                             (long)gridDim.x * kThreads, [&](double x, double y, double z, long) {
+                                 mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x);
+                                 mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
+                                 mn[2] = fmin(mn[2], z); mx[2] = fmax(mx[2], z);
+                             });
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fmin(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmax(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            red[threadIdx.x >> 6][c] = mn[c];
+            red[threadIdx.x >> 6][3 + c] = mx[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        double v = red[0][c];
+        for (int w = 1; w < kThreads / 64; ++w) v = (c < 3) ? fmin(v, red[w][c]) : fmax(v, red[w][c]);
+        partial[((size_t)b * gridDim.x + blockIdx.x) * 6 + c] = v;
+    }
+}
+
 // ---------------------------------------------------------------- grid descriptor
 // desc[b] = lo[3], hi[3], edges_x[nx+1], edges_y[ny+1], edges_z[nz+1]
 // numpy.linspace(lo, hi, n+1): step = (hi-lo)/n ; e_k = k*step + lo ; e_n = hi.
-__global__ void desc_kernel(const double* __restrict__ box, int nx, int ny, int nz, int regular, int from_bounds,
-                            double* __restrict__ desc) {
+// box: [B,6] (nparts == 0) or the per-workgroup partial boxes [B, nparts, 6] of bbox_partial_kernel.
+__global__ void desc_kernel(const double* __restrict__ box, int nparts, int nx, int ny, int nz, int regular,
+                            int from_bounds, double* __restrict__ bbox_out, double* __restrict__ desc) {
     const int b = blockIdx.x;
     const int len = SN_DESC_LEN(nx, ny, nz);
     double* d = desc + (size_t)b * len;
-    const double* bb = box + (size_t)b * 6;
     double lo[3], hi[3];
+    if (nparts == 0) {
+        const double* bb = box + (size_t)b * 6;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        lo[c] = bb[c];
-        hi[c] = bb[3 + c];
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = bb[c];
+            hi[c] = bb[3 + c];
+        }
+    } else {  // ... reduced here (every thread redundantly: nparts is a few dozen)
+        const double* bb = box + (size_t)b * nparts * 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = DBL_MAX;
+            hi[c] = -DBL_MAX;
+        }
+        for (int p = 0; p < nparts; ++p) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = fmin(lo[c], bb[p * 6 + c]);
+                hi[c] = fmax(hi[c], bb[p * 6 + 3 + c]);
+            }
+        }
+        if (bbox_out && threadIdx.x < 3) {
+            bbox_out[b * 6 + threadIdx.x] = lo[threadIdx.x];
+            bbox_out[b * 6 + 3 + threadIdx.x] = hi[threadIdx.x];
+        }
     }
     if (!from_bounds && regular) {
         // pyntcloud regular_bounding_box: margin = max(range) - range; min -= margin/2; max += margin/2
@@ -284,8 +343,10 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
                                                                   const double* __restrict__ desc, int nx, int ny,
                                                                   int nz, int words, int planes, KeepLabels keep,
                                                                   uint32_t* __restrict__ bits_ws,
-                                                                  int32_t* __restrict__ dropped_out,
+                                                                  int32_t* __restrict__ dropped_parts,
                                                                   int32_t* __restrict__ flags) {
+    __shared__ int dropped_blk;
+    if (threadIdx.x == 0) dropped_blk = 0;
     extern __shared__ double smem[];
     const int ne = nx + ny + nz + 3;
     double* edges = smem;
@@ -309,8 +370,12 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
     __syncthreads();
     uint32_t* out = bits_ws + ((size_t)b * kOccParts + blockIdx.x) * (size_t)planes * words;
     for (int i = threadIdx.x; i < words * planes; i += kOccThreads) out[i] = bits[i];
-    if (dropped_out && dropped) atomicAdd(&dropped_out[b], dropped);
-    if (flags && blockIdx.x == 0 && threadIdx.x == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
+    if (dropped) atomicAdd(&dropped_blk, dropped);  // LDS
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dropped_parts[b * kOccParts + blockIdx.x] = dropped_blk;
+        if (flags && blockIdx.x == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
+    }
 }
 
 // OR of the kOccParts partial bitmaps of one tile (plane 0 = occupancy, 1 = towers), word w
@@ -351,8 +416,15 @@ template <typename OT>
 __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* __restrict__ bits_ws, int words,
                                                                 int planes, int rows, int ny, size_t V,
                                                                 OT* __restrict__ occ, OT* __restrict__ gt_occ,
-                                                                int32_t* __restrict__ flags) {
+                                                                int32_t* __restrict__ flags,
+                                                                const int32_t* __restrict__ dropped_parts,
+                                                                int32_t* __restrict__ dropped) {
     const int b = blockIdx.y;
+    if (dropped && blockIdx.x == 0 && threadIdx.x == 0) {
+        int t = 0;
+        for (int p = 0; p < kOccParts; ++p) t += dropped_parts[b * kOccParts + p];
+        dropped[b] = t;
+    }
     const uint32_t* src = bits_ws + (size_t)b * kOccParts * planes * words;
     const int gtid = blockIdx.x * kThreads + threadIdx.x, gstride = gridDim.x * kThreads;
     for (int w = gtid; w < words; w += gstride) {
@@ -375,6 +447,60 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
         empty = (any == 0u);
     }
     if (empty) flags[b] = 0;  // benign race: every writer stores 0
+}
+
+// Rare path of sn_voxel_occupancy: a flagged tile (no empty (z,x) row, so a y column may be full) is redone
+// exactly -- counts by global atomics, column minima, ToFullDense -- by ONE workgroup, in one launch that
+// exits at once for every other tile.  Counts are re-read with agent-scope atomic loads (the atomics
+// execute beyond this CU's L1, which may still hold the zeroed lines).
+template <typename OT, bool kAligned>
+__global__ __launch_bounds__(1024) void occ_fallback_kernel(const double* __restrict__ pts,
+                                                            const double* __restrict__ labels,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const double* __restrict__ desc, int nx, int ny, int nz,
+                                                            KeepLabels keep, const int32_t* __restrict__ flags,
+                                                            int32_t* __restrict__ counts_ws,
+                                                            int32_t* __restrict__ towers_ws, OT* __restrict__ occ,
+                                                            OT* __restrict__ gt_occ) {
+    const int b = blockIdx.x;
+    if (!flags[b]) return;
+    extern __shared__ double smem[];
+    const int ne = nx + ny + nz + 3;
+    double* edges = smem;
+    int* cmin = reinterpret_cast<int*>(smem + ne);  // [ny]
+    const size_t V = (size_t)nx * ny * nz;
+    int32_t* c = counts_ws + (size_t)b * V;
+    int32_t* t = (gt_occ && towers_ws) ? towers_ws + (size_t)b * V : nullptr;
+    for (size_t i = threadIdx.x; i < V; i += blockDim.x) {
+        c[i] = 0;
+        if (t) t[i] = 0;
+    }
+    for (int y = threadIdx.x; y < ny; y += blockDim.x) cmin[y] = INT_MAX;
+    const double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) edges[i] = d[6 + i];
+    __threadfence();
+    __syncthreads();
+    Binner bin;
+    bin.init(edges, d, nx, ny, nz);
+    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)threadIdx.x, (long)blockDim.x,
+                             [&](double x, double y, double z, long i) {
+                                 const int f = bin.flat(x, y, z);
+                                 if (f < 0) return;
+                                 atomicAdd(&c[f], 1);
+                                 if (t && is_kept(labels[i], keep)) atomicAdd(&t[f], 1);
+                             });
+    __threadfence();
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < V; i += blockDim.x)
+        atomicMin(&cmin[i % ny], __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < V; i += blockDim.x) {
+        const int cnt = __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        occ[(size_t)b * V + i] = (cnt > cmin[i % ny]) ? (OT)1 : (OT)0;  // == ToFullDense(normalize_xyz(counts))
+        if (t)
+            gt_occ[(size_t)b * V + i] =
+                (__hip_atomic_load(&t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) ? (OT)1 : (OT)0;
+    }
 }
 
 // ---------------------------------------------------------------- finalize (counting path)
@@ -516,8 +642,8 @@ static int desc_common(const double* box, int B, int nx, int ny, int nz, int reg
     if (!box || !desc) return sn::fail(SN_ERR_INVALID_ARG, "%s: null pointer", who);
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "%s: non-positive extent (B=%d n=%d,%d,%d)", who, B, nx, ny, nz);
-    hipLaunchKernelGGL(desc_kernel, dim3(B), dim3(128), 0, sn::as_stream(stream), box, nx, ny, nz, regular,
-                       from_bounds, desc);
+    hipLaunchKernelGGL(desc_kernel, dim3(B), dim3(128), 0, sn::as_stream(stream), box, 0, nx, ny, nz, regular,
+                       from_bounds, (double*)nullptr, desc);
     return sn::check_launch(who);
 }
 
@@ -529,6 +655,23 @@ extern "C" int sn_voxel_desc(const double* bbox, int B, int nx, int ny, int nz, 
 extern "C" int sn_voxel_desc_from_bounds(const double* bounds, int B, int nx, int ny, int nz, double* desc,
                                          sn_stream_t stream) {
     return desc_common(bounds, B, nx, ny, nz, 0, 1, desc, stream, "sn_voxel_desc_from_bounds");
+}
+
+extern "C" int sn_voxel_prepare(const double* pts, const int64_t* offsets, int B, int nx, int ny, int nz,
+                                int regular, double* partial_ws, double* bbox, double* desc, sn_stream_t stream) {
+    if (!pts || !offsets || !partial_ws || !desc) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_prepare: null pointer");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_prepare: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny, nz);
+    hipStream_t s = sn::as_stream(stream);
+    const int nparts = SN_BBOX_PARTS;
+    dim3 grid(nparts, B);
+    if (aligned16(pts))
+        hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    else
+        hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    hipLaunchKernelGGL(desc_kernel, dim3(B), dim3(128), 0, s, (const double*)partial_ws, nparts, nx, ny, nz, regular,
+                       0, bbox, desc);
+    return sn::check_launch("sn_voxel_prepare");
 }
 
 extern "C" int sn_voxel_scatter(const double* pts, const double* labels, const int64_t* offsets, int B,
@@ -571,7 +714,7 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
                                   const double* desc, int nx, int ny, int nz, const double* keep_labels_host,
                                   int n_keep, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
                                   int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
-                                  int32_t* colstats_ws, sn_stream_t stream) {
+                                  sn_stream_t stream) {
     if (!pts || !offsets || !desc || !bits_ws || !occ)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: null pointer");
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -595,37 +738,37 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
     const int words = (int)(V / 32);
     const int ne = nx + ny + nz + 3;
     hipStream_t s = sn::as_stream(stream);
-    if (dropped && hipMemsetAsync(dropped, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess)
-        return sn::check_launch("sn_voxel_occupancy(memset)");
+    // per-part dropped counts live behind the partial bitmaps in bits_ws (SN_OCC_WS_WORDS accounts for them)
+    int32_t* dropped_parts = reinterpret_cast<int32_t*>(bits_ws + (size_t)B * kOccParts * planes * words);
     const size_t lds1 = (size_t)((ne + 1) & ~1) * sizeof(double) + (size_t)words * planes * sizeof(uint32_t);
-    const bool al = aligned16(pts);
+    const bool al = aligned16(pts) && (!labels || aligned16(labels));
     {
         auto kern = al ? occ_partial_kernel<true> : occ_partial_kernel<false>;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
             hipSuccess)
             return sn::check_launch("sn_voxel_occupancy(hipFuncSetAttribute)");
         hipLaunchKernelGGL(kern, dim3(kOccParts, B), dim3(kOccThreads), lds1, s, pts, labels, offsets, desc, nx, ny,
-                           nz, words, planes, keep, bits_ws, dropped, flags);
+                           nz, words, planes, keep, bits_ws, dropped_parts, flags);
     }
     const int rows = nz * nx;
     int C = (words + kThreads - 1) / kThreads;
     if (C > blocks_per_tile(B, 2048)) C = blocks_per_tile(B, 2048);
     if (out_dtype == SN_U8)
         hipLaunchKernelGGL(occ_finalize_kernel<uint8_t>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes,
-                           rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags);
+                           rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped);
     else
         hipLaunchKernelGGL(occ_finalize_kernel<float>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes, rows,
-                           ny, V, (float*)occ, (float*)gt_occ, flags);
-    // flagged tiles (a y column might be full): redo exactly through the counting kernels, gated per tile
-    if (flags && counts_ws && colstats_ws) {
-        launch_scatter(pts, gt_occ ? labels : nullptr, offsets, B, desc, nx, ny, nz, counts_ws,
-                       gt_occ ? towers_ws : nullptr, keep, nullptr, flags, s);
-        if (out_dtype == SN_U8)
-            launch_finalize<uint8_t>(counts_ws, towers_ws, B, nx, ny, nz, colstats_ws, nullptr, nullptr,
-                                     (uint8_t*)occ, (uint8_t*)gt_occ, flags, s);
-        else
-            launch_finalize<float>(counts_ws, towers_ws, B, nx, ny, nz, colstats_ws, nullptr, nullptr, (float*)occ,
-                                   (float*)gt_occ, flags, s);
+                           ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped);
+    // flagged tiles (a y column might be full): redone exactly by one gated launch
+    if (flags && counts_ws) {
+        const size_t lds3 = (size_t)ne * sizeof(double) + (size_t)ny * sizeof(int);
+        if (lds3 > 64 * 1024) return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_occupancy: edge table too large");
+#define SN_FALLBACK(OT, AL)                                                                                        \
+    hipLaunchKernelGGL((occ_fallback_kernel<OT, AL>), dim3(B), dim3(1024), lds3, s, pts, gt_occ ? labels : nullptr, \
+                       offsets, desc, nx, ny, nz, keep, flags, counts_ws, towers_ws, (OT*)occ, (OT*)gt_occ)
+        if (out_dtype == SN_U8) { if (al) SN_FALLBACK(uint8_t, true); else SN_FALLBACK(uint8_t, false); }
+        else { if (al) SN_FALLBACK(float, true); else SN_FALLBACK(float, false); }
+#undef SN_FALLBACK
     }
     return sn::check_launch("sn_voxel_occupancy");
 }

@@ -88,6 +88,7 @@ class SceneNet(nn.Module):
         d[self.last_lambda] = nn.Parameter(1 - sum(d.values()) + d[self.last_lambda], requires_grad=False)
         self.lambdas_dict = nn.ParameterDict(d)
         self._pack_cache = None
+        self._lambda_cache = None
         self._warned_grad = False
         if plot:
             print(f"Total Number of train params = {self.get_num_total_params()}")
@@ -149,10 +150,18 @@ class SceneNet(nn.Module):
         """[G] f32 in GENEO order; the `last_lambda` entry is 1 - sum(lambdas_dict.values()) + last
         (SCENE_Net.py:331), summed in ParameterDict order like the reference.  Also performs the
         reference's side effect of re-creating lambdas_dict[last_lambda] (SCENE_Net.py:333)."""
+        # ~17 tiny dependent device ops: redone only when a coefficient (or last_lambda) changed since the last
+        # call -- 1 - sum(others) is then already what lambdas_dict[last_lambda] holds.
+        key = (str(device), self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict.values())
+        if self._lambda_cache is not None and self._lambda_cache[0] == key:
+            return self._lambda_cache[1]
         last = 1 - sum(self.lambdas_dict.values()) + self.lambdas_dict[self.last_lambda]
         self.lambdas_dict[self.last_lambda] = nn.Parameter(last.detach(), requires_grad=False)
         vals = [self.lambdas_dict[f"lambda_{g}"].detach() for g in self.geneos]
-        return torch.stack(vals).to(device=device, dtype=torch.float32).contiguous()
+        lam = torch.stack(vals).to(device=device, dtype=torch.float32).contiguous()
+        key = (str(device), self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict.values())
+        self._lambda_cache = (key, lam)
+        return lam
 
     def compute_bank(self, device=None) -> torch.Tensor:
         """[G, kz, kx, ky] f32 on the HIP device (the stack at SCENE_Net.py:324, before the fp64 cast)."""

@@ -95,8 +95,7 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
     if want_t and (batch.labels is None or keep_labels is None):
         raise ValueError("ground-truth grids need labels and keep_labels")
     if bounds is None:
-        bbox = _hip.voxel_bbox(batch.pts, batch.offsets)
-        desc = _hip.voxel_desc(bbox, (nx, ny, nz), regular=True)
+        desc, _ = _hip.voxel_prepare(batch.pts, batch.offsets, (nx, ny, nz), regular=True)
     else:
         desc = _hip.voxel_desc(bounds, (nx, ny, nz), from_bounds=True)
     occupancy_only = (want_occ and not (want_density or want_gt or want_counts)

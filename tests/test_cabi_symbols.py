@@ -23,7 +23,7 @@ def _declared_symbols():
 def test_header_symbols_are_bound_and_exported():
     declared = _declared_symbols()
     assert {"sn_geneo_bank", "sn_conv_bank", "sn_voxel_bbox", "sn_voxel_desc", "sn_voxel_scatter",
-            "sn_voxel_finalize", "sn_last_error", "sn_version"} <= declared
+            "sn_voxel_finalize", "sn_voxel_occupancy", "sn_voxel_prepare", "sn_last_error", "sn_version"} <= declared
     assert declared == set(_hip.SYMBOLS), "ctypes table and header disagree"
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
@@ -53,10 +53,11 @@ def test_argument_checks_need_no_gpu():
     assert lib.sn_voxel_scatter(p, p, p, 1, p, 4, 4, 4, p, p, None, 3, None, None) == -2  # keep list missing
     # occupancy form: 128^3 bits do not fit the LDS bitmap -> caller must take the counting kernels
     assert lib.sn_voxel_occupancy(p, None, p, 1, p, 128, 128, 128, None, 0, p, p, None, 2, None, None, None, None,
-                                  None, None) == -2
+                                  None) == -2
     assert b"LDS bitmap" in lib.sn_last_error()
     assert lib.sn_voxel_occupancy(p, None, p, 1, p, 64, 64, 64, None, 0, p, p, None, 1, None, None, None, None,
-                                  None, None) == -1  # f64 output not offered
+                                  None) == -1  # f64 output not offered
+    assert lib.sn_voxel_prepare(p, p, 1, 64, 64, 0, 1, p, None, p, None) == -1
     assert lib.sn_voxel_finalize(p, None, 1, 4, 4, 4, p, None, p, None, None, None) == -1  # gt w/o towers
 
 

@@ -173,3 +173,14 @@ def test_unaligned_point_buffer(hip_device):
     batch = sna.PointBatch(view, None, offsets, (5_001,))
     g = sna.voxelize_batch(batch, (32, 32, 32), want_occ=True)
     _check_tile(g, 0, xyz, None, (32, 32, 32), None)
+
+
+def test_separate_bbox_and_desc_entry_points_agree_with_prepare(hip_device):
+    tiles = [synthetic_tile(t, n)[0] for t, n in enumerate([7_001, 12_000, 3])]
+    batch = sna.PointBatch.from_tiles(tiles, device=hip_device)
+    bbox = _hip.voxel_bbox(batch.pts, batch.offsets)
+    desc = _hip.voxel_desc(bbox, (16, 32, 8), regular=True)
+    desc2, bbox2 = _hip.voxel_prepare(batch.pts, batch.offsets, (16, 32, 8), want_bbox=True)
+    assert torch.equal(bbox, bbox2) and torch.equal(desc, desc2)
+    for b, t in enumerate(tiles):
+        assert np.array_equal(bbox[b].cpu().numpy(), np.concatenate([t.min(0), t.max(0)]))

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A/B timing of sn_conv_bank (C2 batch, occupancy input) under values of one env knob: interleaved rounds in
+one process, min and median per value (cdna guide rule 24)."""
+import os, sys, statistics, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scene_net_amd import _hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+bank = ((torch.rand(16, 9, 9, 9) - 0.5)).to(dev).contiguous()
+lam = (torch.rand(16) / 16).to(dev)
+dt = torch.uint8 if os.environ.get("KNOB_DTYPE") == "u8" else torch.bool
+x = (torch.rand(32, 1, 64, 64, 64, device=dev) < 0.035).to(dt)
+knob, vals = sys.argv[1], sys.argv[2:]
+for _ in range(60):
+    _hip.conv_bank(x, bank, lam)
+torch.cuda.synchronize()
+res = {v: [] for v in vals}
+for rnd in range(6):
+    for v in vals:
+        os.environ[knob] = v
+        _hip.conv_bank(x, bank, lam)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(15):
+            _hip.conv_bank(x, bank, lam)
+        e1.record()
+        torch.cuda.synchronize()
+        res[v].append(e0.elapsed_time(e1) / 15 * 1000)
+for v in vals:
+    print(f"{knob}={v}: min {min(res[v]):.1f} us  median {statistics.median(res[v]):.1f} us", flush=True)
