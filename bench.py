@@ -32,6 +32,7 @@ from scene_net_amd.pipeline import job_sum, job_time_max  # noqa: E402
 from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_I8_MFMA_TOPS = 5000.0     # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 GENEO_NUM = {"cy": 6, "cone": 5, "neg": 5}
 KERNEL_SIZE = (9, 9, 9)
@@ -176,30 +177,62 @@ def main():
     vox_bytes = (24.0 * args.points + 4.0 * V) * B        # 3.449 MB/tile @ (100k, 64^3)
     conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12
     vox_gbs = vox_bytes / (vox_ms * 1e-3) / 1e9
+    # the int8 kernel issues (R*C*4 slots padded to 64-slot steps) x 3 digit planes per output instead of ntaps
+    chunks = KERNEL_SIZE[0] * KERNEL_SIZE[1] * ((KERNEL_SIZE[2] + 3) // 4)
+    i8_steps = (chunks + 15) // 16
+    executed_ops = 2.0 * V * (i8_steps * 64 * 3) * 16 * B
+    executed_tops = executed_ops / (conv_ms * 1e-3) / 1e12
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from a separate rocprofv3 --pmc pass
+    # the same batch through the fp32-MFMA kernel (general-input path), timed the same way
+    occ_u8 = pipe.voxelize(batch).occ.view(torch.uint8)
+    bank, lam = model.compute_bank(dev), model.effective_lambdas(dev)
+    for _ in range(2):
+        sna._hip.conv_bank(occ_u8, bank, lam, want_act=False, want_out=True)
+    e0, e1 = ev(), ev()
+    e0.record()
+    n32 = max(3, min(10, args.steps))
+    for _ in range(n32):
+        sna._hip.conv_bank(occ_u8, bank, lam, want_act=False, want_out=True)
+    e1.record()
+    torch.cuda.synchronize()
+    conv32_ms = e0.elapsed_time(e1) / n32
+    conv32_tflops = conv_flops / (conv32_ms * 1e-3) / 1e12
+
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from separate rocprofv3 --pmc passes
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get("conv_bank_kernel", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(f)
 
     res = {
         "metric": "voxel-tiles/sec (point cloud -> 64^3 occupancy -> 16-GENEO bank conv -> head)",
         "value": tiles_done / dt, "unit": "tiles/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "i8", "data": "synthetic",
         "config": {"workload": f"C2: {B} tiles/GPU x {args.points} points (fp64 xyz, UTM-scale), {args.grid}^3 voxel "
-                               f"grid, {G} GENEO kernels {KERNEL_SIZE[0]}^3 (cy 6, cone 5, neg 5), fp32 MFMA",
+                               f"grid, {G} GENEO kernels {KERNEL_SIZE[0]}^3 (cy 6, cone 5, neg 5); conv on the int8 "
+                               f"matrix cores: binary occupancy x 24-bit fixed-point weights (3 int8 digits), exact "
+                               f"int32 accumulation, fp32 head",
                    "tiles_per_gpu": B, "points_per_tile": args.points, "grid": list(dims), "geneo_kernels": G,
                    "kernel_size": list(KERNEL_SIZE), "parallelism": f"tile-sharded x{n_gpus}, no collectives"},
         "points_per_s": B * args.points * n_gpus / (vox_ms * 1e-3),
-        "roofline": {"kernel": "conv_bank_kernel (K3)", "bound": "mfma", "achieved": conv_tflops,
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tflops / PEAK_F32_MFMA_TFLOPS,
-                     "traffic": traffic, "launch_ms": conv_ms, "flops_per_launch": conv_flops},
-        "roofline_voxel": {"kernel": "K1: bbox+desc+scatter+finalize (5 launches + memsets)", "bound": "hbm",
-                           "achieved": vox_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": vox_gbs / PEAK_HBM_GBS, "traffic": None, "stage_ms": vox_ms,
-                           "bytes_per_stage": vox_bytes},
+        # dominant kernel.  `achieved` = ALGORITHMIC flops (2*V*729*16 per tile) / launch time; `peak` = dense int8
+        # MFMA peak.  `executed` counts what the kernel really issues (3 digit planes, ky padded 9 -> 12): that
+        # is the matrix-pipe utilisation figure.
+        "roofline": {"kernel": "conv_occ_i8_kernel (K3', v_mfma_i32_16x16x64_i8)", "bound": "mfma",
+                     "achieved": conv_tflops, "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s",
+                     "frac": conv_tflops / PEAK_I8_MFMA_TOPS, "traffic": traffic.get("conv_occ_i8_kernel"),
+                     "launch_ms": conv_ms, "flops_per_launch": conv_flops, "executed": executed_tops,
+                     "executed_frac": executed_tops / PEAK_I8_MFMA_TOPS},
+        "roofline_fp32": {"kernel": "conv_bank_kernel (K3, v_mfma_f32_16x16x4_f32; same batch, general-input path)",
+                          "bound": "mfma", "achieved": conv32_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": conv32_tflops / PEAK_F32_MFMA_TFLOPS,
+                          "traffic": traffic.get("conv_bank_kernel"), "launch_ms": conv32_ms,
+                          "flops_per_launch": conv_flops, "tiles_per_s_conv_only": B / (conv32_ms * 1e-3)},
+        "roofline_voxel": {"kernel": "K1: bbox partials + desc + LDS-bitmap occupancy + finalize + gated fallback "
+                                     "(5 launches)", "bound": "hbm", "achieved": vox_gbs, "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": vox_gbs / PEAK_HBM_GBS, "traffic": traffic.get("voxel_stage"),
+                           "stage_ms": vox_ms, "bytes_per_stage": vox_bytes},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

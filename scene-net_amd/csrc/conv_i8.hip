@@ -44,7 +44,6 @@ struct Shape {
     int C, R, KS;   // chunks per row, kernel rows, MFMA steps (even)
     int PYA, delta; // halo origin = y0 - PYA (PYA = roundup(py, 4)), delta = PYA - py
     int CB;         // bytes between the shifted copies
-    int stagger;    // s_sleep units (64 clk) by which waves 4-7 start each tile late
     int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier
 };
 
@@ -169,12 +168,12 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     __syncthreads();
     // ---- digit table Wd[s][d][l] (16 bytes: slot (q, p)) and chunk offset table coff[s][q] (4 dwords j)
     const int nchunks = s.R * s.C;
-    for (int i = tid; i < KT * 3 * 64; i += kThreads) {
-        const int l = i & 63, d = (i >> 6) % 3, st = i / 192;
+    for (int i = tid; i < KT * 64; i += kThreads) {  // one thread quantises 16 taps once and emits all 3 digit rows
+        const int l = i & 63, st = i >> 6;
         const int g = l & 15, qq = l >> 4;
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        uint32_t w0[4] = {0u, 0u, 0u, 0u}, w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
         if (g < s.G && st < s.KS) {
-            const int F = shiftF[g];
+            const float twoF = ldexpf(1.0f, shiftF[g]);  // exact power of two: wv * 2^F is exact
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int li = slot_index(st, qq, j);
@@ -184,20 +183,22 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     for (int b = 0; b < 4; ++b) {
                         const int dy = 4 * c + b;
                         if (dy < s.ky) {
-                            const float wv = bank_s[g * ntaps + rho * s.ky + dy];
-                            int Q = __float2int_rn(ldexpf(wv, F));
+                            int Q = __float2int_rn(bank_s[g * ntaps + rho * s.ky + dy] * twoF);
                             const int d0 = ((Q + 128) & 255) - 128;
                             Q = (Q - d0) >> 8;
                             const int d1 = ((Q + 128) & 255) - 128;
                             const int d2 = (Q - d1) >> 8;
-                            const int dig = (d == 0) ? d0 : (d == 1) ? d1 : d2;
-                            w[j] |= (uint32_t)(dig & 255) << (8 * b);
+                            w0[j] |= (uint32_t)(d0 & 255) << (8 * b);
+                            w1[j] |= (uint32_t)(d1 & 255) << (8 * b);
+                            w2[j] |= (uint32_t)(d2 & 255) << (8 * b);
                         }
                     }
                 }
             }
         }
-        Wd[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        Wd[(st * 3 + 0) * 64 + l] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+        Wd[(st * 3 + 1) * 64 + l] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        Wd[(st * 3 + 2) * 64 + l] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
     }
     for (int i = tid; i < KT * 4; i += kThreads) {
         const int qq = i & 3, st = i >> 2;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     for (int r = 0; r < 4; ++r) {
         const int g = 4 * q + r;
         sc[r] = scale[g];
-        if (out) lam[r] = (g < s.G) ? lambdas[g] : 0.0f;
+        if (out) lam[r] = (g < s.G) ? lambdas[g] * sc[r] : 0.0f;  // the 2^-F_g rescale rides on lambda (exact)
     }
 
     const int half_tx = s.TX >> 1;
@@ -236,11 +237,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
 
     for (; tile < s.ntiles; tile += gridDim.x) {
         const TileCoord c = tile_coord(s, tile);
-        // Waves w and w+4 share a SIMD and run the same program from the same barrier: left alone they stay in
-        // lockstep (both in the MFMA loop, then both in the VALU epilogue, matrix pipe idle).  Starting the
-        // second half late by about one epilogue keeps one wave's epilogue under its partner's MFMAs.
-        if (__builtin_amdgcn_readfirstlane(wave) >= kWaves / 2)
-            for (int i = 0; i < s.stagger; ++i) __builtin_amdgcn_s_sleep(8);
         for (int round = wave; round < nrounds; round += kWaves) {
             const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
             const uint8_t* xb = xs + lanebase + (lz * XP + lx) * YPB;
@@ -251,13 +247,15 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
 #pragma unroll
                 for (int v = 0; v < NV; ++v) acc[d][v] = i32x4{0, 0, 0, 0};
 
-            auto gather = [&](const int4& co, i32x4 (&xv)[NV]) {
+            // operands of accumulator tiles 2p, 2p+1 (two y-strips of one x-row): 4 ds_read2_b32
+            auto gather_pair = [&](const int4& co, i32x4 (&xv)[NV], int p) {
                 const uint8_t* p0 = xb + co.x;
                 const uint8_t* p1 = xb + co.y;
                 const uint8_t* p2 = xb + co.z;
                 const uint8_t* p3 = xb + co.w;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
+                for (int h = 0; h < 2; ++h) {
+                    const int v = 2 * p + h;
                     const int to = (v >> 2) * YPB + (v & 3) * 16;
                     xv[v] = i32x4{*reinterpret_cast<const int*>(p0 + to), *reinterpret_cast<const int*>(p1 + to),
                                   *reinterpret_cast<const int*>(p2 + to), *reinterpret_cast<const int*>(p3 + to)};
@@ -270,42 +268,45 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     w[d] = i32x4{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
                 }
             };
-            auto mma = [&](const i32x4 (&w)[3], const i32x4 (&xv)[NV]) {
+            auto mma_pair = [&](const i32x4 (&w)[3], const i32x4 (&xv)[NV], int p) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
-                        acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv[v], acc[d][v], 0, 0, 0);
+                        acc[d][2 * p + h] =
+                            __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv[2 * p + h], acc[d][2 * p + h], 0, 0, 0);
             };
 
-            // software pipeline, ping-pong by 2 (KS is even; the tables carry kTablePad zero steps)
-            i32x4 wa[3], wb[3], xa[NV], xb2[NV];
-            int4 ca = coff[1 * 4 + q], cb;
+            // Software pipeline at TILE-PAIR granularity.  lgkmcnt is a 4-bit counter: with a whole step's 20 LDS
+            // reads in flight a counted wait cannot name "all but the last 20", so the prefetch distance is two
+            // sub-blocks instead: sub-block (t, p) = {the 4 halo reads of pair p+2 of step t (p < 2) or of pair
+            // p-2 of step t+1 (p >= 2); the 6 MFMAs of pair p of step t}.  One operand set X[8] serves every step
+            // (a pair's registers are refilled two sub-blocks after their last use); the digit rows / chunk
+            // offsets of the next step are requested at sub-block 0, a full step (or two sub-blocks) ahead.
+            i32x4 wa[3], wb[3], X[NV];
+            int4 ca = coff[q], cb;
             load_w(0, wa);
-            gather(coff[q], xa);
-            // Each half step: 20 LDS reads for the NEXT step and 24 MFMAs of the CURRENT one.  Issued as two
-            // blocks the LDS queue fills while the matrix pipe drains and vice versa; the group barriers below
-            // make the scheduler interleave them (3 MFMAs, then up to 3 LDS reads, eight times).
-#define SN_I8_INTERLEAVE()                                                  \
-    _Pragma("unroll") for (int gi = 0; gi < 8; ++gi) {                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                  \
-    }
+            gather_pair(ca, X, 0);
+            gather_pair(ca, X, 1);
+#define SN_SB(GC, GP, W, MP)                 \
+    gather_pair(GC, X, GP);                  \
+    mma_pair(W, X, MP);                      \
+    __builtin_amdgcn_sched_barrier(0);
             for (int st = 0; st < s.KS; st += 2) {
                 load_w(st + 1, wb);
-                cb = coff[(st + 2) * 4 + q];
-                gather(ca, xb2);
-                mma(wa, xa);
-                SN_I8_INTERLEAVE();
-                __builtin_amdgcn_sched_barrier(0);
+                cb = coff[(st + 1) * 4 + q];
+                SN_SB(ca, 2, wa, 0)
+                SN_SB(ca, 3, wa, 1)
+                SN_SB(cb, 0, wa, 2)
+                SN_SB(cb, 1, wa, 3)
                 load_w(st + 2, wa);
-                ca = coff[(st + 3) * 4 + q];
-                gather(cb, xa);
-                mma(wb, xb2);
-                SN_I8_INTERLEAVE();
-                __builtin_amdgcn_sched_barrier(0);
+                ca = coff[(st + 2) * 4 + q];
+                SN_SB(cb, 2, wb, 0)
+                SN_SB(cb, 3, wb, 1)
+                SN_SB(ca, 0, wb, 2)
+                SN_SB(ca, 1, wb, 3)
             }
-#undef SN_I8_INTERLEAVE
+#undef SN_SB
 
             // ---- epilogue: recombine the digits, then the same head as the fp32 kernel
             const int gz = c.z0 + lz;
@@ -317,15 +318,14 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(acc[d][v]));
                 continue;
             }
+            // S = S2*65536 + (S1*256 + S0): the low pair fits int32 (|.| < 2^25), one fp32 rounding each
             float val[NV][4];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float f = (float)acc[2][v][r] * 65536.0f;
-                    f = fmaf((float)acc[1][v][r], 256.0f, f);
-                    f += (float)acc[0][v][r];
-                    val[v][r] = f * sc[r];
+                    const int low = acc[1][v][r] * 256 + acc[0][v][r];
+                    val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);  // unscaled: x 2^-F_g below
                 }
             if (act) {
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                             const int g = 4 * q + r;
                             if (g < s.G)
                                 act[((size_t)c.b * s.G + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy] =
-                                    (OT)val[v][r];
+                                    (OT)(val[v][r] * sc[r]);
                         }
                     }
                 }
@@ -365,6 +365,9 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 }
             }
         }
+        // [measured] prefetching the next halo into registers across the rounds (16 VGPRs) makes hipcc spill
+        // (the kernel wants > 400 registers at 2 waves/SIMD) and a 1-wave/SIMD build runs 1.9x slower: the halo
+        // refill therefore stays a synchronous phase (~5 us per tile, 13 % of the kernel at C2).
         if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile
         const int next = tile + gridDim.x;
         if (next < s.ntiles && !(s.dbg & 2)) halo_fill(xs, x, s, tile_coord(s, next), tid, XP, rows);
@@ -411,8 +414,6 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     s.delta = s.PYA - py;
     if (s.delta + 15 + 48 + 4 * s.C + 3 > YPB) return 1;
     s.nyt = (Y + TY - 1) / TY;
-    const char* st = getenv("SN_CONV_I8_STAGGER");
-    s.stagger = st ? atoi(st) : 0;  // x 8 x 64 clk
     const char* dbg = getenv("SN_CONV_I8_DBG");
     s.dbg = dbg ? atoi(dbg) : 0;
     const int cus = num_cus();
