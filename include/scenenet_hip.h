@@ -41,8 +41,12 @@ typedef enum {
  * int8 matrix cores.  SN_U8 is a general 0..255 byte grid. */
 typedef enum { SN_F32 = 0, SN_F64 = 1, SN_U8 = 2, SN_OCC8 = 3 } sn_dtype;
 
-/* GENEO kinds, in SceneNet's key order (core/models/SCENE_Net.py:259-272). */
-typedef enum { SN_GENEO_CY = 0, SN_GENEO_CONE = 1, SN_GENEO_NEG = 2 } sn_geneo_kind;
+/* GENEO kinds: 0-2 = cylinderv2 / arrow / negSpherev2 of SceneNet (core/models/SCENE_Net.py:259-272);
+ * 3-5 = cylinder_kernel / cone_kernel / neg_sphere_kernel of the v1 module SCENE_Net (SCENE_Net.py:158-170). */
+typedef enum {
+    SN_GENEO_CY = 0, SN_GENEO_CONE = 1, SN_GENEO_NEG = 2,
+    SN_GENEO_CY_V1 = 3, SN_GENEO_CONE_V1 = 4, SN_GENEO_NEG_V1 = 5
+} sn_geneo_kind;
 
 /* Parameter slots of one GENEO: params[g * SN_NPARAM + slot] (fp32). */
 enum {
@@ -66,8 +70,9 @@ int sn_device_count(void);
  * replaces: GENEO_Layer.compute_kernel (core/models/SCENE_Net.py:103-106) over
  *           cylinderv2.compute_kernel (core/models/geneos/cylinder.py:162-176),
  *           arrow.compute_kernel      (core/models/geneos/arrow.py:228-252),
- *           negSpherev2.compute_kernel(core/models/geneos/neg_sphere.py:185-199)
- *           and the torch.stack at SCENE_Net.py:324.
+ *           negSpherev2.compute_kernel(core/models/geneos/neg_sphere.py:185-199),
+ *           the v1 generators cylinder.py:84-103, arrow.py:173-205, neg_sphere.py:133-158,
+ *           and the torch.stack at SCENE_Net.py:324 / :211.
  * params [G, SN_NPARAM] f32, kinds [G] i32 -> bank [G, kz, kx, ky] f32.
  * status (nullable) [G] i32: 0 ok, 1 = int(apex) outside [0, kz] (the reference
  * raises from torch.stack there; the kernel clamps and flags).

@@ -6,12 +6,14 @@ Import as `scene_net_amd` (shim package at the repo root).
 """
 from . import _hip
 from ._hip import HipLibraryError, LIB_PATH
-from .geneos import GENEO_kernel_torch, arrow, cylinderv2, negSpherev2
-from .scene_net import GENEO_Layer, SceneNet
+from .geneos import (GENEO_kernel_torch, arrow, cone_kernel, cylinder_kernel, cylinderv2, neg_sphere_kernel,
+                     negSpherev2)
+from .scene_net import GENEO_Layer, SCENE_Net, SCENE_Net_Class, SCENENetQuantile, SceneNet
 from .transforms import ToFullDense, ToTensor, Voxelization
 from .voxelization import PointBatch, VoxelGrids, hist_on_voxel, prob_to_label, reg_on_voxel, voxelize_batch
 from .pipeline import ScenePipeline, shard_range
 
-__all__ = ["SceneNet", "GENEO_Layer", "GENEO_kernel_torch", "cylinderv2", "arrow", "negSpherev2", "Voxelization",
+__all__ = ["SceneNet", "SCENE_Net", "SCENENetQuantile", "SCENE_Net_Class", "cylinder_kernel", "cone_kernel",
+           "neg_sphere_kernel", "GENEO_Layer", "GENEO_kernel_torch", "cylinderv2", "arrow", "negSpherev2", "Voxelization",
            "ToTensor", "ToFullDense", "hist_on_voxel", "reg_on_voxel", "prob_to_label", "voxelize_batch",
            "PointBatch", "VoxelGrids", "ScenePipeline", "shard_range", "HipLibraryError", "LIB_PATH"]

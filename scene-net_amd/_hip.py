@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libscenenet_hip.so")
 
 SN_F32, SN_F64, SN_U8, SN_OCC8 = 0, 1, 2, 3
 SN_GENEO_CY, SN_GENEO_CONE, SN_GENEO_NEG = 0, 1, 2
+SN_GENEO_CY_V1, SN_GENEO_CONE_V1, SN_GENEO_NEG_V1 = 3, 4, 5
 SN_P_RADIUS, SN_P_SIGMA, SN_P_APEX, SN_P_CONE_RADIUS, SN_P_CONE_INC, SN_P_NEG_FACTOR = 0, 1, 2, 3, 4, 5
 SN_NPARAM = 8
 

@@ -21,6 +21,13 @@ __device__ __forceinline__ float geneo_gauss(float r2, float rad, float sig) {
     return sig * expf((r2 * r2) * c);
 }
 
+// v1 generators: exp((r^2 - rad^2)^2 * (-1 / (2 sig^2)))   (cylinder.py:72-79, arrow.py:157-168, neg_sphere.py:123-131)
+__device__ __forceinline__ float geneo_ring(float r2, float rad, float sig) {
+    float cx = r2 - rad * rad;
+    float c = -1.0f / (2.0f * (sig * sig));
+    return expf((cx * cx) * c);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -45,45 +52,57 @@ __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __res
     const float sigma = p[SN_P_SIGMA];
     const float cx = (kx - 1) * 0.5f, cy = (ky - 1) * 0.5f, cz = (kz - 1) * 0.5f;
 
+    const bool is_cone = (kind == SN_GENEO_CONE || kind == SN_GENEO_CONE_V1);
+    const bool is_neg = (kind == SN_GENEO_NEG || kind == SN_GENEO_NEG_V1);
     int hc = 0;
-    float cone_radius = 0.f, tan_inc = 0.f, neg = 0.f;
-    if (kind == SN_GENEO_CONE) {
+    float cone_radius = 0.f, tan_inc = 0.f, neg = 0.f, inc_pi = 0.f;
+    if (is_cone) {
         hc = (int)p[SN_P_APEX];  // truncation, arrow.py:235
         int bad = (hc < 0 || hc > kz);
         hc = min(max(hc, 0), kz);
         if (status && tid == 0) status[g] = bad;
         cone_radius = p[SN_P_CONE_RADIUS];
-        float inc = fminf(fmaxf(p[SN_P_CONE_INC], 0.0f), 0.499f);  // arrow.py:244
+        float inc = fminf(fmaxf(p[SN_P_CONE_INC], 0.0f), 0.499f);  // arrow.py:244 (v2 only)
         tan_inc = tanf(inc * kPi);
+        inc_pi = p[SN_P_CONE_INC] * kPi;  // v1: not clamped, arrow.py:189
     } else {
         if (status && tid == 0) status[g] = 0;
-        if (kind == SN_GENEO_NEG) neg = p[SN_P_NEG_FACTOR];
+        if (is_neg) neg = p[SN_P_NEG_FACTOR];
     }
 
     for (int idx = tid; idx < vol; idx += kThreads) {
         float v;
-        if (kind == SN_GENEO_NEG) {
+        if (is_neg) {
             // output element idx of the row-major [kz,kx,ky] view takes flat-column row idx, whose
             // index triple is (k_z, i_x, j_y) = (idx % kz, (idx / kz) % kx, idx / (kz*kx))
             float dz = (float)(idx % kz) - cz;
             float dx = (float)((idx / kz) % kx) - cx;
             float dy = (float)(idx / (kz * kx)) - cy;
-            v = (-neg) * geneo_gauss(dx * dx + dy * dy + dz * dz, radius, sigma);
+            const float r2 = dx * dx + dy * dy + dz * dz;
+            v = (kind == SN_GENEO_NEG) ? (-neg) * geneo_gauss(r2, radius, sigma) : geneo_ring(r2, radius, sigma);
         } else {
             int z = idx / nfloor, n = idx - z * nfloor;
             // element n of the row-major [kx,ky] view takes flat-column row n = (i_x, j_y) = (n % kx, n / kx)
             float dx = (float)(n % kx) - cx;
             float dy = (float)(n / kx) - cy;
-            float rad = radius;
-            if (kind == SN_GENEO_CONE && z < kz - hc) rad = cone_radius * (float)z * tan_inc;
-            v = geneo_gauss(dx * dx + dy * dy, rad, sigma);
+            const float r2 = dx * dx + dy * dy;
+            if (kind == SN_GENEO_CY || kind == SN_GENEO_CONE) {
+                float rad = radius;
+                if (kind == SN_GENEO_CONE && z < kz - hc) rad = cone_radius * (float)z * tan_inc;
+                v = geneo_gauss(r2, rad, sigma);
+            } else {  // v1: ring gaussian; cone slices use sigma_h, h = 0 nearest the cylinder (prepend order)
+                float sig = sigma;
+                if (kind == SN_GENEO_CONE_V1 && z < kz - hc)
+                    sig = cone_radius * sinf(inc_pi / (float)(2 + (kz - hc - 1 - z)));
+                v = geneo_ring(r2, radius, sig);
+            }
         }
         vals[idx] = v;
     }
     __syncthreads();
 
-    const int nseg = (kind == SN_GENEO_NEG) ? 1 : kz;
-    const int seg_len = (kind == SN_GENEO_NEG) ? vol : nfloor;
+    const int nseg = is_neg ? 1 : kz;
+    const int seg_len = is_neg ? vol : nfloor;
     const int wave = tid >> 6, lane = tid & 63;
     for (int s = wave; s < nseg; s += kThreads / 64) {
         float acc = 0.f;
@@ -98,6 +117,8 @@ __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __res
         float mean;
         if (kind == SN_GENEO_NEG)
             mean = (seg_sum[0] + neg) / (float)vol;  // sum_negfactor, neg_sphere.py:181-182
+        else if (kind == SN_GENEO_NEG_V1)
+            mean = seg_sum[0] / (float)vol + neg;  // sum_zero(.) - neg_factor, neg_sphere.py:151
         else
             mean = seg_sum[idx / nfloor] / (float)nfloor;  // sum_zero, cylinder.py:81-82
         out[idx] = vals[idx] - mean;

@@ -28,11 +28,11 @@ def pack_params(kind: int, params: Dict[str, torch.Tensor], device) -> torch.Ten
     slots[_hip.SN_P_RADIUS] = _as_f32_scalar(params["radius"], device)
     sigma = params.get("sigma")
     slots[_hip.SN_P_SIGMA] = _as_f32_scalar(1.0 if sigma is None else sigma, device)  # default sigma = 1
-    if kind == _hip.SN_GENEO_CONE:
+    if kind in (_hip.SN_GENEO_CONE, _hip.SN_GENEO_CONE_V1):
         slots[_hip.SN_P_APEX] = _as_f32_scalar(params["apex"], device)
         slots[_hip.SN_P_CONE_RADIUS] = _as_f32_scalar(params["cone_radius"], device)
         slots[_hip.SN_P_CONE_INC] = _as_f32_scalar(params["cone_inc"], device)
-    elif kind == _hip.SN_GENEO_NEG:
+    elif kind in (_hip.SN_GENEO_NEG, _hip.SN_GENEO_NEG_V1):
         slots[_hip.SN_P_NEG_FACTOR] = _as_f32_scalar(params["neg_factor"], device)
     return torch.stack(slots)
 
@@ -65,7 +65,7 @@ class GENEO_kernel_torch:
         kinds = torch.tensor([self.KIND], dtype=torch.int32, device=self.device)
         status = torch.zeros(1, dtype=torch.int32, device=self.device)
         bank = _hip.geneo_bank(params, kinds, self.kernel_size, status)
-        if self.KIND == _hip.SN_GENEO_CONE and int(status.item()) != 0:
+        if self.KIND in (_hip.SN_GENEO_CONE, _hip.SN_GENEO_CONE_V1) and int(status.item()) != 0:
             # the reference fails in torch.tile / torch.stack with a wrong kernel depth (arrow.py:241-250)
             raise RuntimeError(f"arrow: int(apex) outside [0, {self.kernel_size[0]}]")
         return bank[0]
@@ -231,3 +231,29 @@ class negSpherev2(GENEO_kernel_torch):
 
 KIND_OF_CLASS.update({"cy": cylinderv2.KIND, "cone": arrow.KIND, "neg": negSpherev2.KIND})
 CLASS_OF_KEY = {"cy": cylinderv2, "cone": arrow, "neg": negSpherev2}  # SCENE_Net.py:259-272
+
+
+# --------------------------------------------------------------------------- #
+# v1 generators used by the v1 module `SCENE_Net` (core/models/SCENE_Net.py:158-170)
+# --------------------------------------------------------------------------- #
+class cylinder_kernel(cylinderv2):
+    """cylinder.py:30-140: ring gaussian exp((|p-c|^2 - radius^2)^2 / (-2 sigma^2)), no sigma prefactor."""
+
+    KIND = _hip.SN_GENEO_CY_V1
+
+
+class cone_kernel(arrow):
+    """arrow.py:30-205: cylinder below, ring gaussians of shrinking sigma_h = cone_radius sin(cone_inc pi / (2+h)) above;
+    cone_inc is not clamped."""
+
+    KIND = _hip.SN_GENEO_CONE_V1
+
+
+class neg_sphere_kernel(negSpherev2):
+    """neg_sphere.py:29-158: 3-D ring gaussian, sum_zero, minus neg_factor."""
+
+    KIND = _hip.SN_GENEO_NEG_V1
+
+
+CLASS_OF_KEY_V1 = {"cy": cylinder_kernel, "cone": cone_kernel, "neg": neg_sphere_kernel}  # SCENE_Net.py:158-170
+KIND_OF_CLASS.update({"cy_v1": cylinder_kernel.KIND, "cone_v1": cone_kernel.KIND, "neg_v1": neg_sphere_kernel.KIND})

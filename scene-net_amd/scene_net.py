@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .geneos import CLASS_OF_KEY, GENEO_kernel_torch, pack_params
+from .geneos import CLASS_OF_KEY, CLASS_OF_KEY_V1, GENEO_kernel_torch, pack_params
 
 
 class GENEO_Layer(nn.Module):
@@ -63,6 +63,10 @@ class GENEO_Layer(nn.Module):
 class SceneNet(nn.Module):
     """SCENE_Net.py:229-339."""
 
+    GENEO_CLASSES = CLASS_OF_KEY
+    # lambda init range as a function of the number of GENEOs (SCENE_Net.py:276-277)
+    LAMBDA_RANGE = staticmethod(lambda n: (-2 / n, 1 / n))
+
     def __init__(self, geneo_num=None, kernel_size=None, plot=False):
         super().__init__()
         self.sizes = {"cy": 1, "cone": 1, "neg": 1} if geneo_num is None else geneo_num
@@ -70,14 +74,13 @@ class SceneNet(nn.Module):
             self.kernel_size = kernel_size
         self.geneos: Mapping[str, GENEO_Layer] = nn.ModuleDict()
         for key in self.sizes:
-            if key in CLASS_OF_KEY:
+            if key in self.GENEO_CLASSES:
                 for i in range(self.sizes[key]):
-                    self.geneos[f"{key}_{i}"] = GENEO_Layer(CLASS_OF_KEY[key], kernel_size=kernel_size)
+                    self.geneos[f"{key}_{i}"] = GENEO_Layer(self.GENEO_CLASSES[key], kernel_size=kernel_size)
 
         # --- convex coefficients (SCENE_Net.py:274-293), same RNG draws
         num_lambdas = sum(self.sizes.values())
-        lambda_init_max = 1 / num_lambdas
-        lambda_init_min = -2 / num_lambdas
+        lambda_init_min, lambda_init_max = self.LAMBDA_RANGE(num_lambdas)
         lambdas = (lambda_init_max - lambda_init_min) * torch.rand(num_lambdas, dtype=torch.float) + lambda_init_min
         lambdas = [nn.Parameter(lamb) for lamb in lambdas]
         self.lambda_names = [f"lambda_{key}_{i}" for key, val in self.sizes.items() for i in range(val)]
@@ -137,7 +140,7 @@ class SceneNet(nn.Module):
                     raise KeyError(f"GENEO {layer.name}: missing mandatory parameter {m}")
             rows.append(pack_params(kind, layer.geneo_params, device))
             kinds.append(kind)
-            if kind == _hip.SN_GENEO_CONE:
+            if kind in (_hip.SN_GENEO_CONE, _hip.SN_GENEO_CONE_V1):
                 hc = int(layer.geneo_params["apex"].detach().to(torch.int).item())
                 if hc < 0 or hc > int(layer.kernel_size[0]):
                     raise RuntimeError(f"arrow: int(apex)={hc} outside [0, {layer.kernel_size[0]}]")
@@ -185,3 +188,84 @@ class SceneNet(nn.Module):
             act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
                                       out_dtype=out_dtype)
         return (out, act) if return_bank_activations else out
+
+
+class SCENE_Net(SceneNet):
+    """The v1 module, SCENE_Net.py:121-226: same forward, v1 generators (cylinder_kernel, cone_kernel,
+    neg_sphere_kernel), lambdas initialised in [0, 0.6] (SCENE_Net.py:174-177)."""
+
+    GENEO_CLASSES = CLASS_OF_KEY_V1
+    LAMBDA_RANGE = staticmethod(lambda n: (0, 0.6))
+
+    def __init__(self, geneo_num=None, kernel_size=None, plot=False, device=None):
+        super().__init__(geneo_num, kernel_size, plot)
+        self.device = device
+        if device is not None:
+            self.to(device)
+
+    def get_geneo_nums(self):
+        return self.sizes
+
+    def get_dict_parameters(self):
+        return dict([(n, param.data.item()) for n, param in self.named_parameters()])
+
+
+class SCENENetQuantile(nn.Module):
+    """SCENE_Net.py:347-415: an ensemble of v1 SCENE_Nets, one per quantile; forward stacks them on the channel axis."""
+
+    def __init__(self, geneo_num=None, kernel_size=None, qs=torch.tensor([0.1, 0.5, 0.9]), plot=False, device=None):
+        super().__init__()
+        self.scnets = nn.ModuleList([SCENE_Net(geneo_num, kernel_size, plot) for _ in range(len(qs))])
+        if device is not None:
+            self.scnets.to(device)
+        self.qs = qs
+        self.device = device
+
+    def get_num_total_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def get_dict_parameters(self):
+        return dict([(n, param.data.item()) for n, param in self.named_parameters()])
+
+    def get_cvx_coefficients(self):
+        return [scnet.get_cvx_coefficients() for scnet in self.scnets]
+
+    def get_geneo_params(self):
+        return [scnet.get_geneo_params() for scnet in self.scnets]
+
+    def forward(self, x: torch.Tensor):
+        preds = [torch.squeeze(net(x), dim=1) for net in self.scnets]
+        return torch.stack(preds, dim=1).to(torch.float32)  # the reference fills a float32 torch.empty
+
+
+class SCENE_Net_Class(nn.Module):
+    """SCENE_Net.py:421-466: thresholded v1 SCENE_Net, (gnet(x) >= tau).to(x.dtype)."""
+
+    def __init__(self, geneo_num=None, plot=True, gnet_requires_grad=True):
+        super().__init__()
+        self.gnet = SCENE_Net(geneo_num, plot=False)  # the reference passes `plot` as kernel_size (SCENE_Net.py:427)
+        if not gnet_requires_grad:
+            for param in self.gnet.parameters():
+                param.requires_grad = False
+        tau_min, tau_max = 0.2, 0.6
+        self.tau = nn.Parameter((tau_max - tau_min) * torch.rand(1, dtype=torch.float)[0])
+
+    def get_threshold(self):
+        return self.tau
+
+    def get_geneo_nums(self):
+        return self.gnet.sizes
+
+    def get_cvx_coefficients(self):
+        return self.gnet.lambdas_dict
+
+    def get_geneo_params(self):
+        return nn.ParameterDict(dict([(name.replace(".", "_"), p) for name, p in self.gnet.named_parameters()
+                                      if "lambda" not in name]))
+
+    def get_dict_parameters(self):
+        return dict([(n, param.data.item()) for n, param in self.gnet.named_parameters()])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pred = self.gnet(x)
+        return (pred >= self.tau.to(pred.device)).to(x.dtype if x.dtype.is_floating_point else pred.dtype)

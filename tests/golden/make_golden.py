@@ -73,6 +73,22 @@ def dump_kernels():
             key = f"neg|{ks}|{i}"
             out[key] = k.detach().cpu().numpy()
             meta.append((key, "neg", ks, p))
+    # v1 generators (SCENE_Net v1): cylinder_kernel, cone_kernel, neg_sphere_kernel
+    for ks in [(9, 9, 9), (9, 5, 5), (6, 5, 6), (4, 6, 5)]:
+        for i, p in enumerate(CY_PARAMS):
+            k = cylinder.cylinder_kernel("cy", ks, **{n: T(v) for n, v in p.items()}).kernel
+            key = f"cy_v1|{ks}|{i}"
+            out[key] = k.detach().cpu().numpy(); meta.append((key, "cy_v1", ks, p))
+        for i, p in enumerate(CONE_PARAMS):
+            if int(p["apex"]) > ks[0] or p["cone_inc"] <= 0:
+                continue
+            k = arrow.cone_kernel("cone", ks, **{n: T(v) for n, v in p.items()}).kernel
+            key = f"cone_v1|{ks}|{i}"
+            out[key] = k.detach().cpu().numpy(); meta.append((key, "cone_v1", ks, p))
+        for i, p in enumerate(NEG_PARAMS):
+            k = neg_sphere.neg_sphere_kernel("neg", ks, **{n: T(v) for n, v in p.items()}).kernel
+            key = f"neg_v1|{ks}|{i}"
+            out[key] = k.detach().cpu().numpy(); meta.append((key, "neg_v1", ks, p))
     np.savez_compressed(os.path.join(OUT, "geneo_kernels.npz"), **out)
     import json
     with open(os.path.join(OUT, "geneo_kernels_meta.json"), "w") as f:
@@ -163,6 +179,33 @@ def dump_forward():
     print("geneo_forward.npz:", sorted({k.split('/')[0] for k in out}))
 
 
+def dump_forward_v1():
+    """SCENE_Net (v1 module, SCENE_Net.py:121-226) forward with explicit parameters."""
+    from core.models.SCENE_Net import SCENE_Net
+    torch.manual_seed(0)
+    model = SCENE_Net({"cy": 2, "cone": 1, "neg": 1}, (9, 7, 7), device=torch.device("cpu"))
+    gp = {"cy_0": dict(radius=2.5, sigma=1.8), "cy_1": dict(radius=1.0, sigma=0.7),
+          "cone_0": dict(radius=2.0, sigma=1.4, apex=4.0, cone_radius=3.0, cone_inc=0.2),
+          "neg_0": dict(radius=2.0, sigma=0.9, neg_factor=0.2)}
+    lam = {"lambda_cy_0": 0.11, "lambda_cy_1": 0.27, "lambda_cone_0": 0.35, "lambda_neg_0": 0.05}
+    set_model(model, gp, lam, "lambda_cy_1")
+    rng = np.random.default_rng(31)
+    x = (rng.random((2, 1, 14, 12, 20)) < 0.12).astype(np.float64)
+    with torch.no_grad():
+        kernels = torch.stack([model.geneos[g].compute_kernel() for g in model.geneos])
+        conv = torch.nn.functional.conv3d(torch.from_numpy(x), kernels, padding="same")
+        out = model(torch.from_numpy(x))
+    names = list(model.geneos.keys())
+    np.savez_compressed(os.path.join(OUT, "geneo_forward_v1.npz"), x=x.astype(np.uint8), bank=kernels.numpy(),
+                        conv=conv.numpy(), out=out.numpy(), names=np.array(names),
+                        lambdas=np.array([lam[f"lambda_{n}"] for n in names], dtype=np.float32),
+                        last=np.array(names.index("cy_1")), kernel_size=np.array((9, 7, 7)))
+    import json
+    with open(os.path.join(OUT, "geneo_forward_v1_meta.json"), "w") as f:
+        json.dump(dict(geneo_params=gp, names=names, state_dict_keys=list(model.state_dict().keys())), f, indent=0)
+    print("geneo_forward_v1.npz")
+
+
 def dump_module_contract():
     """State-dict keys / accessor names the drop-in must keep."""
     torch.manual_seed(3)
@@ -233,4 +276,5 @@ if __name__ == "__main__":
     dump_voxel_normalize()
     dump_kernels()
     dump_forward()
+    dump_forward_v1()
     dump_module_contract()

@@ -80,6 +80,41 @@ def test_fused_pipeline_matches_reference_chain(hip_device, golden_dir):
         assert (out[b].double().cpu() - ref[0]).abs().max().item() < TOL
 
 
+def test_v1_module_and_wrappers(hip_device, golden_dir):
+    """SCENE_Net (v1), SCENENetQuantile, SCENE_Net_Class: golden forward of the reference's v1 module."""
+    import json
+    F = np.load(os.path.join(golden_dir, "geneo_forward_v1.npz"))
+    with open(os.path.join(golden_dir, "geneo_forward_v1_meta.json")) as f:
+        meta = json.load(f)
+    torch.manual_seed(0)
+    model = sna.SCENE_Net({"cy": 2, "cone": 1, "neg": 1}, (9, 7, 7))
+    assert list(model.state_dict().keys()) == meta["state_dict_keys"]
+    names = [str(n) for n in F["names"]]
+    with torch.no_grad():
+        for n in names:
+            for k, v in meta["geneo_params"][n].items():
+                model.geneos[n].geneo_params[k].fill_(v)
+        for n, v in zip(names, F["lambdas"]):
+            model.lambdas_dict[f"lambda_{n}"].fill_(float(v))
+    model.last_lambda = f"lambda_{names[int(F['last'])]}"
+    model = model.to(hip_device)
+    x = torch.from_numpy(F["x"].astype(np.float64)).to(hip_device)
+    out, act = model(x, return_bank_activations=True)
+    assert (act.cpu() - torch.from_numpy(F["conv"])).abs().max().item() < TOL
+    assert (out.cpu() - torch.from_numpy(F["out"])).abs().max().item() < TOL
+    outb = model(x.bool())  # int8 path on the same occupancy
+    assert (outb.double().cpu() - torch.from_numpy(F["out"])).abs().max().item() < TOL
+    # thresholded head and quantile ensemble are thin wrappers over the same forward
+    torch.manual_seed(1)
+    cls = sna.SCENE_Net_Class({"cy": 1, "cone": 1, "neg": 1}, plot=False).to(hip_device)
+    pred = cls.gnet(x)
+    assert torch.equal(cls(x), (pred >= cls.tau).to(x.dtype))
+    q = sna.SCENENetQuantile({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5), device=hip_device)
+    yq = q(x)
+    assert yq.shape == (2, 3, 14, 12, 20) and yq.dtype == torch.float32
+    assert torch.equal(yq[:, 1], q.scnets[1](x)[:, 0].float())
+
+
 def test_smoke_entry(hip_device):
     import __graft_entry__
     __graft_entry__.smoke()

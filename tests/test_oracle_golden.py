@@ -33,11 +33,13 @@ def test_kernel_invariants(golden_dir):
     # the reference's commented-out asserts (cylinder.py:98-101) and neg-sphere's sum (neg_sphere.py:181-182)
     for m in _kernel_cases(golden_dir):
         k = go.geneo_kernel(m["kind"], m["kernel_size"], m["params"]).double()
-        if m["kind"] in ("cy", "cone"):
+        if m["kind"] in ("cy", "cone", "cy_v1", "cone_v1"):
             assert k.sum(dim=(1, 2)).abs().max() < 1e-4, m["key"]  # every z-slice sums to 0 (fp32 rounding)
-        else:
+        elif m["kind"] == "neg":
             assert abs(k.sum().item() + m["params"]["neg_factor"]) < 1e-4, m["key"]
-        if m["kind"] == "cy":
+        else:  # neg_v1: sum_zero(.) - neg_factor on every element
+            assert abs(k.sum().item() + m["params"]["neg_factor"] * k.numel()) < 1e-3, m["key"]
+        if m["kind"] in ("cy", "cy_v1"):
             assert torch.equal(k[0], k[-1])
 
 
@@ -59,6 +61,20 @@ def test_scenenet_forward_bit_exact(golden_dir, tag):
     lam = go.effective_lambdas(F[f"{tag}/lambdas"], int(F[f"{tag}/last"]), names)
     assert lam[int(F[f"{tag}/last"])].item() == pytest.approx(float(F[f"{tag}/lambda_last_after"]), abs=0)
     assert out.min() >= 0 and out.max() < 1  # relu(tanh(.))
+
+
+def test_v1_module_forward_bit_exact(golden_dir):
+    """SCENE_Net (v1 module) forward, SCENE_Net.py:209-226, with the v1 generators."""
+    F = np.load(os.path.join(golden_dir, "geneo_forward_v1.npz"))
+    with open(os.path.join(golden_dir, "geneo_forward_v1_meta.json")) as f:
+        meta = json.load(f)
+    names = [str(n) for n in F["names"]]
+    specs = [(n.split("_")[0] + "_v1", meta["geneo_params"][n]) for n in names]
+    ks = tuple(int(k) for k in F["kernel_size"])
+    x = torch.from_numpy(F["x"].astype(np.float64))
+    out, conv = go.scenenet_forward(x, specs, ks, F["lambdas"], int(F["last"]), return_bank=True, names=names)
+    assert np.array_equal(go.geneo_bank(specs, ks).numpy(), F["bank"])
+    assert np.array_equal(conv.numpy(), F["conv"]) and np.array_equal(out.numpy(), F["out"])
 
 
 def test_linearity_fast_path_matches(golden_dir):
