@@ -91,7 +91,8 @@ int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int 
  * out_dtype (SN_F32 or SN_F64).  x_dtype SN_F32 / SN_F64 / SN_U8: fp32 MFMA accumulation
  * (v_mfma_f32_16x16x4_f32).  x_dtype SN_OCC8 (values in {0,1}): weights as 24-bit fixed point in three
  * int8 digits, exact int32 accumulation on v_mfma_i32_16x16x64_i8, recombined in fp32.
- * G <= 16 per call in this revision.
+ * Any G: one MFMA row block holds 16 kernels, larger banks run as ceil(G/16) launches with the raw partial sum
+ * carried in `out` (the last launch applies relu(tanh)).
  * ------------------------------------------------------------------------- */
 int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lambdas,
                  int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
@@ -174,6 +175,14 @@ int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* o
                        uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
                        int32_t* flags, int32_t* dropped,
                        int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream);
+
+/* Grid -> points: out[c, i] = grid[b(i), c, vz, vx, vy] for every point i of the batch, binned exactly as the
+ * scatter binned it (same desc); points outside the edge table get `fill`.  grid [B,channels,nz,nx,ny] and
+ * out [channels, total] are of `dtype` (SN_F32 | SN_F64).  The reference only has the voxel-list direction
+ * (vxg_to_xyz, utils/voxelization.py:328-360) and prob_to_label (:304-323); per-point read-back of the
+ * prediction (BASELINE config 4) is defined here. */
+int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets, int B,
+                     const double* desc, int nx, int ny, int nz, double fill, void* out, sn_stream_t stream);
 
 #ifdef __cplusplus
 }

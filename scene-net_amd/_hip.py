@@ -36,6 +36,7 @@ SYMBOLS = {
     "sn_voxel_finalize": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
 }
 SN_OCC_PARTS = 8
 SN_BBOX_PARTS = 32
@@ -239,3 +240,17 @@ def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[flo
                                    _ptr(counts), _ptr(towers), _stream())
     _check(rc, "sn_voxel_occupancy")
     return occ, gt_occ, flags, dropped
+
+
+def gather_points(grid: torch.Tensor, pts: torch.Tensor, offsets: torch.Tensor, desc: torch.Tensor,
+                  fill: float = 0.0) -> torch.Tensor:
+    """grid [B,C,nz,nx,ny] (f32|f64) -> per-point values [C, total] via the scatter's binning (sn_gather_points)."""
+    if grid.dim() != 5 or grid.dtype not in (torch.float32, torch.float64):
+        raise HipLibraryError("grid must be [B,C,nz,nx,ny] float32/float64")
+    B, C, nz, nx, ny = grid.shape
+    out = torch.empty((C, pts.shape[0]), dtype=grid.dtype, device=grid.device)
+    rc = load().sn_gather_points(_ptr(grid, None, "grid"), _DT[grid.dtype], C, _ptr(pts, torch.float64, "pts"),
+                                 _ptr(offsets, torch.int64, "offsets"), B, _ptr(desc, torch.float64, "desc"),
+                                 nx, ny, nz, float(fill), _ptr(out), _stream())
+    _check(rc, "sn_gather_points")
+    return out

@@ -44,6 +44,8 @@ struct ConvShape {
     int nzt, nxt, nyt;   // tiles per axis
     int ntiles;          // B * nzt * nxt * nyt
     int T4;              // tap steps of 4, rounded up to even (ping-pong unroll)
+    int Gtot, g0;        // this launch handles kernels g0 .. g0+G-1 of a bank of Gtot (act channel stride)
+    int head;            // bit 0: add the partial sum already in `out`; bit 1: apply relu(tanh) (else store raw)
 };
 
 template <typename T>
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
                         for (int r = 0; r < 4; ++r) {
                             const int g = 4 * q + r;
                             if (g < s.G)
-                                act[((size_t)c.b * s.G + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy] =
+                                act[((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy] =
                                     (OT)acc[v][r];
                         }
                     }
@@ -316,8 +318,12 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
                                 a3 = sums[4 * xr + 3];
                     const float sv = (q == 0) ? a0 : (q == 1) ? a1 : (q == 2) ? a2 : a3;
                     const int gx = c.x0 + lx + xr, gy = c.y0 + q * 16 + n;
-                    if (gx < s.X && gy < s.Y)
-                        out[(size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy] = (OT)fmaxf(tanhf(sv), 0.0f);
+                    if (gx < s.X && gy < s.Y) {
+                        OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
+                        float t = sv;
+                        if (s.head & 1) t += (float)*o;  // kernels of earlier 16-groups (G > 16)
+                        *o = (OT)((s.head & 2) ? fmaxf(tanhf(t), 0.0f) : t);
+                    }
                 }
             }
         }
@@ -391,8 +397,12 @@ void set_tile(ConvShape& s, int tz, int tx) {
 }  // namespace
 
 namespace sn {
-int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
-                int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream);  // conv_i8.hip
+int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
+                int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                hipStream_t stream);  // conv_i8.hip
+int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
+                    int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                    sn_stream_t stream);
 }
 
 extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,
@@ -403,7 +413,26 @@ extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const
     if (out && !lambdas) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank: out needs lambdas");
     if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank: non-positive extent");
-    if (G > 16) return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_bank: G=%d > 16 (one MFMA row block per call)", G);
+    if (G > 16) {
+        // one MFMA row block holds 16 kernels: run the bank in groups of 16; `out` carries the raw partial sum
+        // between the launches and the last one applies relu(tanh)
+        const size_t ntaps = (size_t)kz * kx * ky;
+        for (int g0 = 0; g0 < G; g0 += 16) {
+            const int gc = (G - g0 < 16) ? G - g0 : 16;
+            const int head = (g0 > 0 ? 1 : 0) | (g0 + gc >= G ? 2 : 0);
+            const int rc = sn::conv_bank_group(x, x_dtype, bank + g0 * ntaps, lambdas ? lambdas + g0 : nullptr, B, Z, X,
+                                               Y, gc, G, g0, head, kz, kx, ky, act, out, out_dtype, stream);
+            if (rc != SN_OK) return rc;
+        }
+        return SN_OK;
+    }
+    return sn::conv_bank_group(x, x_dtype, bank, lambdas, B, Z, X, Y, G, G, 0, 2, kz, kx, ky, act, out, out_dtype,
+                               stream);
+}
+
+int sn::conv_bank_group(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,
+                        int Y, int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out,
+                        int out_dtype, sn_stream_t stream) {
     if (ky - 1 > YP - TY) return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_bank: ky=%d > %d", ky, YP - TY + 1);
     if (out_dtype != SN_F32 && out_dtype != SN_F64)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank: out_dtype %d", out_dtype);
@@ -413,8 +442,8 @@ extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const
         // binary occupancy bytes: int8 matrix cores (exact integer accumulation of 24-bit fixed-point weights)
         const char* no_i8 = getenv("SN_CONV_NO_I8");
         if (!(no_i8 && no_i8[0] == '1')) {
-            const int rc = sn::conv_occ_i8((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, act, out,
-                                           out_dtype, sn::as_stream(stream));
+            const int rc = sn::conv_occ_i8((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky,
+                                           act, out, out_dtype, sn::as_stream(stream));
             if (rc <= 0) return rc;
         }
         x_dtype = SN_U8;  // shape not served by the int8 kernel: same bytes through the fp32 kernel
@@ -422,6 +451,7 @@ extern "C" int sn_conv_bank(const void* x, int x_dtype, const float* bank, const
 
     ConvShape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
+    s.Gtot = Gtot; s.g0 = g0; s.head = head;
     s.T4 = (((kz * kx * ky + 3) / 4) + 1) & ~1;
     s.nyt = (Y + TY - 1) / TY;
     const int cus = num_cus();

@@ -44,6 +44,7 @@ struct Shape {
     int C, R, KS;   // chunks per row, kernel rows, MFMA steps (even)
     int PYA, delta; // halo origin = y0 - PYA (PYA = roundup(py, 4)), delta = PYA - py
     int CB;         // bytes between the shifted copies
+    int Gtot, g0, head;  // kernel group of a larger bank: act channel stride/offset; head bits (see conv.hip)
     int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier
 };
 
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                         for (int r = 0; r < 4; ++r) {
                             const int g = 4 * q + r;
                             if (g < s.G)
-                                act[((size_t)c.b * s.G + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy] =
+                                act[((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy] =
                                     (OT)(val[v][r] * sc[r]);
                         }
                     }
@@ -360,8 +361,12 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                                 a3 = sums[4 * xr + 3];
                     const float sv = (q == 0) ? a0 : (q == 1) ? a1 : (q == 2) ? a2 : a3;
                     const int gx = c.x0 + lx + xr, gy = c.y0 + q * 16 + n;
-                    if (gx < s.X && gy < s.Y)
-                        out[(size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy] = (OT)fmaxf(tanhf(sv), 0.0f);
+                    if (gx < s.X && gy < s.Y) {
+                        OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
+                        float t = sv;
+                        if (s.head & 1) t += (float)*o;
+                        *o = (OT)((s.head & 2) ? fmaxf(tanhf(t), 0.0f) : t);
+                    }
                 }
             }
         }
@@ -400,11 +405,12 @@ int num_cus() {
 namespace sn {
 
 // returns SN_OK, an error, or 1 when this shape is not served by the int8 kernel (caller falls back to fp32)
-int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
-                int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream) {
+int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
+                int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream) {
     if (Y % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 3) != 0 || G > 16) return 1;
     Shape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
+    s.Gtot = Gtot; s.g0 = g0; s.head = head;
     s.C = (ky + 3) / 4;
     if (s.C > kMaxC) return 1;
     s.R = kz * kx;

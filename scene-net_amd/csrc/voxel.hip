@@ -570,6 +570,32 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const int32_t* __res
     }
 }
 
+// ---------------------------------------------------------------- grid -> points (per-point gather)
+// out[i] = grid[b, vz(i), vx(i), vy(i)] with the SAME binning as the scatter (so a point reads the voxel it fell
+// into); points outside the edge table get `fill`.
+template <typename T, bool kAligned>
+__global__ __launch_bounds__(kThreads) void gather_points_kernel(const T* __restrict__ grid, int channels,
+                                                                 const double* __restrict__ pts,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 const double* __restrict__ desc, int nx, int ny,
+                                                                 int nz, T fill, T* __restrict__ out) {
+    extern __shared__ double edges[];
+    const int b = blockIdx.y;
+    const double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+    load_edges(edges, d, nx + ny + nz + 3, kThreads);
+    Binner bin;
+    bin.init(edges, d, nx, ny, nz);
+    const size_t V = (size_t)nx * ny * nz;
+    const T* g = grid + (size_t)b * channels * V;
+    const long total = offsets[gridDim.y];
+    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kThreads + threadIdx.x,
+                             (long)gridDim.x * kThreads, [&](double x, double y, double z, long i) {
+                                 const int f = bin.flat(x, y, z);
+                                 for (int c = 0; c < channels; ++c)
+                                     out[(size_t)c * total + i] = (f < 0) ? fill : g[(size_t)c * V + f];
+                             });
+}
+
 inline int blocks_per_tile(int B, int target) {
     int per = (target + B - 1) / B;
     return per < 1 ? 1 : (per > 256 ? 256 : per);
@@ -771,4 +797,26 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
 #undef SN_FALLBACK
     }
     return sn::check_launch("sn_voxel_occupancy");
+}
+
+extern "C" int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets,
+                                int B, const double* desc, int nx, int ny, int nz, double fill, void* out,
+                                sn_stream_t stream) {
+    if (!grid || !pts || !offsets || !desc || !out) return sn::fail(SN_ERR_INVALID_ARG, "sn_gather_points: null pointer");
+    if (B <= 0 || channels <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_gather_points: non-positive extent");
+    if (dtype != SN_F32 && dtype != SN_F64)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_gather_points: dtype %d (SN_F32 | SN_F64)", dtype);
+    const size_t lds = (size_t)(nx + ny + nz + 3) * sizeof(double);
+    if (lds > 64 * 1024) return sn::fail(SN_ERR_UNSUPPORTED, "sn_gather_points: edge table > 64 KiB");
+    hipStream_t s = sn::as_stream(stream);
+    dim3 grd(blocks_per_tile(B, 1024), B);
+    const bool al = aligned16(pts);
+#define SN_GATHER(T, AL)                                                                                              \
+    hipLaunchKernelGGL((gather_points_kernel<T, AL>), grd, dim3(kThreads), lds, s, (const T*)grid, channels, pts,    \
+                       offsets, desc, nx, ny, nz, (T)fill, (T*)out)
+    if (dtype == SN_F32) { if (al) SN_GATHER(float, true); else SN_GATHER(float, false); }
+    else { if (al) SN_GATHER(double, true); else SN_GATHER(double, false); }
+#undef SN_GATHER
+    return sn::check_launch("sn_gather_points");
 }

@@ -45,8 +45,8 @@ def test_argument_checks_need_no_gpu():
     assert lib.sn_conv_bank(None, 0, None, None, 1, 8, 8, 8, 1, 3, 3, 3, None, None, 0, None) == -1
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.sn_conv_bank(p, 0, p, p, 1, 8, 8, 8, 17, 3, 3, 3, p, p, 0, None) == -2  # G > 16
-    assert b"G=17" in lib.sn_last_error()
+    assert lib.sn_conv_bank(p, 0, p, p, 1, 8, 8, 70, 4, 3, 3, 26, p, p, 0, None) == -2  # ky > 25
+    assert b"ky=26" in lib.sn_last_error()
     assert lib.sn_conv_bank(p, 0, p, p, 1, 8, 8, 8, 4, 3, 3, 3, None, None, 0, None) == -1  # no output
     assert lib.sn_conv_bank(p, 0, p, p, 0, 8, 8, 8, 4, 3, 3, 3, p, p, 0, None) == -1  # B = 0
     assert lib.sn_voxel_scatter(p, None, p, 1, p, 4, 4, 4, p, p, None, 0, None, None) == -1  # towers w/o labels
