@@ -184,6 +184,25 @@ int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* o
 int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets, int B,
                      const double* desc, int nx, int ny, int nz, double fill, void* out, sn_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Backward (training config; reference: autograd through SceneNet.forward, SCENE_Net.py:322-339, and the
+ * generator graphs cylinder.py / arrow.py / neg_sphere.py).  By linearity the whole backward needs ONE
+ * correlation C[t] = sum_{b,v} delta[b,v] x[b, v + t - p]:  dL/dK_g = lambda_g C,  dL/dlambda_g = <K_g, C>.
+ * ------------------------------------------------------------------------- */
+
+/* C [kz,kx,ky] f32.  gout = dL/dout [B,1,Z,X,Y] f32; when `out` (the forward output, f32) is given,
+ * delta = gout * (out > 0) * (1 - out^2) (the relu(tanh) derivative) else delta = gout.  x as in sn_conv_bank.
+ * partial_ws: scratch [sn_conv_corr_blocks(B,Z,X,Y), kz*kx*ky] f32; the block partials are summed in a fixed
+ * order (bit-reproducible). */
+int sn_conv_corr(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X, int Y,
+                 int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream);
+int sn_conv_corr_blocks(int B, int Z, int X, int Y);
+
+/* Generator Jacobians: dparams [G, SN_NPARAM] f32 = d<dW, bank(params)>/dparams for dW [G,kz,kx,ky] f32
+ * (apex has no gradient: it is truncated to an index, arrow.py:235, and non-trainable, arrow.py:134). */
+int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
+                      const float* dW, float* dparams, sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,9 @@ SYMBOLS = {
     "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
+    "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
+    "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
 }
 SN_OCC_PARTS = 8
 SN_BBOX_PARTS = 32
@@ -254,3 +257,27 @@ def gather_points(grid: torch.Tensor, pts: torch.Tensor, offsets: torch.Tensor, 
                                  nx, ny, nz, float(fill), _ptr(out), _stream())
     _check(rc, "sn_gather_points")
     return out
+
+
+def conv_corr(x: torch.Tensor, gout: torch.Tensor, out: Optional[torch.Tensor], kernel_size: Sequence[int]):
+    """C [kz,kx,ky] f32 = sum_{b,v} delta[b,v] x[b, v+t-p]  (sn_conv_corr); gout/out [B,1,Z,X,Y] f32."""
+    B, _, Z, X, Y = x.shape
+    kz, kx, ky = (int(k) for k in kernel_size)
+    nblk = load().sn_conv_corr_blocks(B, Z, X, Y)
+    ws = torch.empty((nblk, kz * kx * ky), dtype=torch.float32, device=x.device)
+    C = torch.empty((kz, kx, ky), dtype=torch.float32, device=x.device)
+    rc = load().sn_conv_corr(_ptr(x, None, "x"), _DT[x.dtype], _ptr(gout, torch.float32, "gout"),
+                             _ptr(out, torch.float32, "out"), B, Z, X, Y, kz, kx, ky, _ptr(ws), _ptr(C), _stream())
+    _check(rc, "sn_conv_corr")
+    return C
+
+
+def geneo_bank_bwd(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int], dW: torch.Tensor):
+    """dparams [G, SN_NPARAM] f32 from dW [G,kz,kx,ky] f32 (sn_geneo_bank_bwd)."""
+    G = params.shape[0]
+    kz, kx, ky = (int(k) for k in kernel_size)
+    dparams = torch.empty((G, SN_NPARAM), dtype=torch.float32, device=params.device)
+    rc = load().sn_geneo_bank_bwd(_ptr(params, torch.float32, "params"), _ptr(kinds, torch.int32, "kinds"), G, kz, kx,
+                                  ky, _ptr(dW, torch.float32, "dW"), _ptr(dparams), _stream())
+    _check(rc, "sn_geneo_bank_bwd")
+    return dparams

@@ -7,7 +7,6 @@ sn_geneo_bank (K2) and sn_conv_bank (K3, conv + convex head fused).  No CPU path
 """
 from __future__ import annotations
 
-import warnings
 from typing import Mapping, Optional, Tuple
 
 import torch
@@ -92,7 +91,6 @@ class SceneNet(nn.Module):
         self.lambdas_dict = nn.ParameterDict(d)
         self._pack_cache = None
         self._lambda_cache = None
-        self._warned_grad = False
         if plot:
             print(f"Total Number of train params = {self.get_num_total_params()}")
 
@@ -172,15 +170,52 @@ class SceneNet(nn.Module):
         params, kinds = self.packed_params(device)
         return _hip.geneo_bank(params, kinds, self.kernel_size_of_bank())
 
+    # ------------------------------------------------------------------ differentiable host logic (training)
+    def _packed_params_autograd(self, device) -> torch.Tensor:
+        """[G, SN_NPARAM] f32 stacked out of the nn.Parameters themselves, so autograd routes the HIP
+        generator Jacobians (sn_geneo_bank_bwd) back to every scalar."""
+        self.packed_params(device)  # validation (mandatory parameters, apex range) + kinds cache
+        zero = torch.zeros((), dtype=torch.float32, device=device)
+        rows = []
+        for layer in self.geneos.values():
+            kind, gp = layer.geneo_class.KIND, layer.geneo_params
+            slots = [zero] * _hip.SN_NPARAM
+            on = lambda t: t.to(device=device, dtype=torch.float32)  # noqa: E731
+            slots[_hip.SN_P_RADIUS] = on(gp["radius"])
+            slots[_hip.SN_P_SIGMA] = on(gp["sigma"]) if "sigma" in gp else zero + 1.0
+            if kind in (_hip.SN_GENEO_CONE, _hip.SN_GENEO_CONE_V1):
+                slots[_hip.SN_P_APEX] = on(gp["apex"]).detach()
+                slots[_hip.SN_P_CONE_RADIUS] = on(gp["cone_radius"])
+                slots[_hip.SN_P_CONE_INC] = on(gp["cone_inc"])
+            elif kind in (_hip.SN_GENEO_NEG, _hip.SN_GENEO_NEG_V1):
+                slots[_hip.SN_P_NEG_FACTOR] = on(gp["neg_factor"])
+            rows.append(torch.stack(slots))
+        return torch.stack(rows)
+
+    def _effective_lambdas_autograd(self, device) -> torch.Tensor:
+        """SCENE_Net.py:329-335 with the graph kept: the last coefficient is 1 - sum(others), so its gradient
+        flows (negated) into every other lambda, exactly as in the reference."""
+        last = 1 - sum(self.lambdas_dict.values()) + self.lambdas_dict[self.last_lambda]
+        vals = [last if f"lambda_{g}" == self.last_lambda else self.lambdas_dict[f"lambda_{g}"] for g in self.geneos]
+        lam = torch.stack(vals).to(device=device, dtype=torch.float32)
+        self.lambdas_dict[self.last_lambda] = nn.Parameter(last.detach(), requires_grad=False)  # SCENE_Net.py:333
+        self._lambda_cache = None
+        return lam
+
     def forward(self, x: torch.Tensor, return_bank_activations: bool = False):
-        """x [B,1,Z,X,Y] on a HIP device -> relu(tanh(sum_i lambda_i conv3d(x, K_i))) [B,1,Z,X,Y], same dtype.
-        With return_bank_activations=True also returns conv [B,G,Z,X,Y] (SCENE_Net.py:325)."""
+        """x [B,1,Z,X,Y] on a HIP device -> relu(tanh(sum_i lambda_i conv3d(x, K_i))) [B,1,Z,X,Y], same dtype
+        (f32 for bool / u8 input).  With return_bank_activations=True also returns conv [B,G,Z,X,Y]
+        (SCENE_Net.py:325; not differentiable).  Under autograd the output carries the graph to every trainable
+        scalar: backward = sn_conv_corr + sn_geneo_bank_bwd."""
         if not x.is_cuda:
             raise _hip.HipLibraryError("SceneNet.forward runs on the HIP device only (no CPU fallback): move x to cuda")
-        if torch.is_grad_enabled() and not self._warned_grad and any(p.requires_grad for p in self.parameters()):
-            warnings.warn("scene-net_amd: forward path only -- the HIP conv has no backward yet (SURVEY 8f-2); "
-                          "the output does not require grad")
-            self._warned_grad = True
+        ks = self.kernel_size_of_bank()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = self._packed_params_autograd(x.device)
+            lam = self._effective_lambdas_autograd(x.device)
+            kinds = self.packed_params(x.device)[1]
+            out, act = _GeneoForwardFn.apply(x.contiguous(), params, lam, kinds, ks, return_bank_activations)
+            return (out, act) if return_bank_activations else out
         with torch.no_grad():
             bank = self.compute_bank(x.device)
             lam = self.effective_lambdas(x.device)
@@ -188,6 +223,35 @@ class SceneNet(nn.Module):
             act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
                                       out_dtype=out_dtype)
         return (out, act) if return_bank_activations else out
+
+
+class _GeneoForwardFn(torch.autograd.Function):
+    """K2 + K3 forward, (sn_conv_corr, sn_geneo_bank_bwd) backward.  Inputs with gradients: params [G,8], lam [G]."""
+
+    @staticmethod
+    def forward(ctx, x, params, lam, kinds, kernel_size, want_act):
+        p = params.detach().contiguous()
+        l = lam.detach().contiguous()
+        bank = _hip.geneo_bank(p, kinds, kernel_size)
+        out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
+        act, out = _hip.conv_bank(x, bank, l, want_act=want_act, want_out=True, out_dtype=out_dtype)
+        ctx.save_for_backward(x, out, bank, p, l, kinds)
+        ctx.kernel_size = tuple(kernel_size)
+        if act is not None:
+            ctx.mark_non_differentiable(act)
+        return out, act
+
+    @staticmethod
+    def backward(ctx, gout, _gact=None):
+        x, out, bank, p, l, kinds = ctx.saved_tensors
+        G = bank.shape[0]
+        C = _hip.conv_corr(x, gout.to(torch.float32).contiguous(), out.to(torch.float32).contiguous(),
+                           ctx.kernel_size)                      # [kz,kx,ky]
+        c = C.reshape(1, -1)
+        dlam = (bank.reshape(G, -1) * c).sum(dim=1)              # dL/dlambda_g = <K_g, C>
+        dW = (l.reshape(G, 1) * c).reshape(bank.shape).contiguous()  # dL/dK_g = lambda_g C
+        dparams = _hip.geneo_bank_bwd(p, kinds, ctx.kernel_size, dW)
+        return None, dparams, dlam, None, None, None
 
 
 class SCENE_Net(SceneNet):
