@@ -205,7 +205,7 @@ def main():
             traffic = json.load(f)
 
     res = {
-        "metric": "voxel-tiles/sec (point cloud -> 64^3 occupancy -> 16-GENEO bank conv -> head)",
+        "metric": f"voxel-tiles/sec (point cloud -> {args.grid}^3 occupancy -> {G}-GENEO bank conv -> head)",
         "value": tiles_done / dt, "unit": "tiles/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i8", "data": "synthetic",

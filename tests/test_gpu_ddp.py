@@ -1,0 +1,63 @@
+"""Training config on the N>1 path: the module under DistributedDataParallel (tiles sharded per rank, gradient
+all-reduce of the ~50 scalars).  Two ranks share the one GPU of the test box, so the process group is gloo here;
+on a node it is nccl (= RCCL) with one rank per GPU -- the model code is the same."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import scene_net_amd as sna
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    torch.manual_seed(7)  # same initial model on every rank
+    model = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)).to(dev)
+    ddp = DDP(model, device_ids=[0])
+    g = torch.Generator().manual_seed(100)  # the global batch, identical on every rank; each takes its shard
+    x = (torch.rand(4, 1, 12, 12, 24, generator=g) < 0.2)
+    y = (torch.rand(4, 1, 12, 12, 24, generator=g) < 0.1).float()
+    lo, hi = sna.shard_range(4, rank, world)
+    loss = ((ddp(x[lo:hi].to(dev)) - y[lo:hi].to(dev)) ** 2).mean()
+    loss.backward()
+    grads = {n: float(p.grad) for n, p in model.named_parameters() if p.grad is not None}
+    # single-process reference of the same global step: mean over the two equal shards == mean of shard means
+    torch.manual_seed(7)
+    ref = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)).to(dev)
+    ((ref(x.to(dev)) - y.to(dev)) ** 2).mean().backward()
+    ref_grads = {n: float(p.grad) for n, p in ref.named_parameters() if p.grad is not None}
+    q.put((rank, grads, ref_grads))
+    dist.destroy_process_group()
+
+
+def test_ddp_gradients_are_the_global_batch_gradients():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, g0, ref0), (_, g1, _) = res
+    assert set(g0) == set(ref0) and len(g0) >= 9
+    for n in g0:
+        assert g0[n] == g1[n], n  # all-reduced: identical on both ranks
+        assert abs(float(g0[n]) - float(ref0[n])) <= 1e-5 + 1e-3 * abs(float(ref0[n])), (n, float(g0[n]), float(ref0[n]))
