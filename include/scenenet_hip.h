@@ -167,7 +167,7 @@ int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_counts, int B,
  *               global atomics, column minima) by one gated launch when counts_ws (and towers_ws with
  *               gt_occ) is given: counts_ws, towers_ws [B,nz,nx,ny] i32 scratch (nullable).
  *   dropped     (nullable) [B] i32: points outside the edge table. */
-#define SN_OCC_PARTS 8
+#define SN_OCC_PARTS 16
 #define SN_OCC_WS_WORDS(B, V, planes) ((size_t)(B) * SN_OCC_PARTS * ((planes) * ((V) / 32) + 1))
 int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* offsets, int B,
                        const double* desc, int nx, int ny, int nz,

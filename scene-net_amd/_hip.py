@@ -41,7 +41,7 @@ SYMBOLS = {
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
 }
-SN_OCC_PARTS = 8
+SN_OCC_PARTS = 16
 SN_BBOX_PARTS = 32
 OCC_MAX_WORDS = 16 * 1024
 

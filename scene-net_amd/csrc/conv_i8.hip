@@ -31,7 +31,10 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int TY = 64;        // y extent of a workgroup tile
 constexpr int NV = 8;         // accumulator tiles per wave round: 2 x-rows x 4 y-strips
-constexpr int YPB = 96;       // halo row stride in bytes (24 dwords: rows 2 apart differ by 16 banks)
+// halo row stride in bytes, two builds of the kernel:
+//   96 (24 dwords: rows 2 apart differ by 16 banks) -- ky up to 24, halo refilled synchronously from global;
+//   80 (20 dwords: rows 4 apart differ by 16 banks) -- ky up to 12; the 16 KiB saved hold a STAGING copy of the
+//      next tile's raw rows, filled by LDS-DMA (global_load_lds, no VGPRs) while the MFMA rounds run.
 constexpr int kMaxC = 6;      // chunks per kernel row: ky <= 24
 constexpr int kCopyPad = 16;  // copy stride = tile bytes + 16: the 4 copies start 4 banks apart
 constexpr int kMaxLds = 160 * 1024;
@@ -65,14 +68,19 @@ __device__ uint32_t g_zero_word[4] = {0u, 0u, 0u, 0u};
 
 // slot (step s, lane group q, dword j) -> chunk list index.  The list is c-major (all rows of chunk column
 // 0, then column 1, ...), and the two lane groups that share an LDS cycle (q = 0,1 and q = 2,3) are placed 2
-// list entries = 2 halo rows = 48 dwords = 16 banks apart.
+// (YPB = 96) or 4 (YPB = 80) list entries = halo rows = 16 banks apart.
+template <int YPB>
 __device__ __forceinline__ int slot_index(int s, int q, int j) {
-    const int perm = ((q & 1) << 1) | (q >> 1);  // 0,2,1,3
-    return s * 16 + j * 4 + perm;
+    if (YPB == 96) {
+        const int perm = ((q & 1) << 1) | (q >> 1);  // 0,2,1,3: lane groups q, q^1 are 2 rows apart
+        return s * 16 + j * 4 + perm;
+    }
+    return s * 16 + q * 4 + j;  // YPB = 80: lane groups q, q^1 are 4 rows apart
 }
 
 // halo tile: copies[k][r][i] (bytes), copy k = tile shifted by k bytes.  Global rows are read as aligned
 // dwords (Y % 4 == 0, origin y0 - PYA is a multiple of 4): out-of-grid dwords come from a zero word.
+template <int YPB>
 __device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_t* __restrict__ x, const Shape& s,
                                           const TileCoord& c, int tid, int XP, int rows) {
     constexpr int DW = YPB / 4;
@@ -110,7 +118,48 @@ __device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_
     }
 }
 
-template <typename OT>
+// LDS-DMA of the next tile's raw rows: item idx = (row r, dword i) lands at stage[idx]; a wave-instruction
+// writes 64 consecutive dwords (LDS address = wave-uniform base + lane*4), the global address is per lane
+// (out-of-grid dwords are fetched from a zero word).  No VGPR destination, nothing to keep live.
+template <int YPB>
+__device__ __forceinline__ void halo_dma_issue(uint32_t* __restrict__ stage, const uint8_t* __restrict__ x,
+                                               const Shape& s, const TileCoord& c, int wave, int lane, int XP,
+                                               int rows) {
+    constexpr int DW = YPB / 4;
+    const int total = rows * DW;
+    for (int base = wave * 64; base < total; base += kThreads) {
+        const int idx = base + lane;
+        const int r = idx / DW, i = idx - r * DW;
+        const int zz = r / XP, xx = r - zz * XP;
+        const int gz = c.z0 - (s.kz - 1) / 2 + zz, gx = c.x0 - (s.kx - 1) / 2 + xx;
+        const int gy = c.y0 - s.PYA + 4 * i;
+        const bool ok = (idx < total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y);
+        const uint8_t* row = x + (((size_t)c.b * s.Z + gz) * s.X + gx) * s.Y;
+        const void* src = ok ? static_cast<const void*>(row + gy) : static_cast<const void*>(g_zero_word);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + base), 4, 0, 0);
+    }
+}
+
+// staging -> the four byte-shifted copies (pure LDS traffic)
+template <int YPB>
+__device__ __forceinline__ void halo_expand(uint8_t* __restrict__ xs, const uint32_t* __restrict__ stage,
+                                            const Shape& s, int tid, int rows) {
+    constexpr int DW = YPB / 4;
+    const int total = rows * DW;
+    const int cs = s.CB >> 2;
+    for (int idx = tid; idx < total; idx += kThreads) {
+        const uint32_t lo = stage[idx];
+        const uint32_t hi = stage[idx + 1];  // last dword of a row: its shifted copies are never read back
+        uint32_t* d = reinterpret_cast<uint32_t*>(xs) + idx;
+        d[0] = lo;
+        d[cs] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+        d[2 * cs] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+        d[3 * cs] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+    }
+}
+
+template <typename OT, int YPB, bool kStage>
 __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __restrict__ x,
                                                                const float* __restrict__ bank,
                                                                const float* __restrict__ lambdas, Shape s,
@@ -130,6 +179,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     float* scale = reinterpret_cast<float*>(coff + KT * 4);               // [16]   2^-F_g
     int* shiftF = reinterpret_cast<int*>(scale + 16);                     // [16]   F_g
     uint8_t* xs = reinterpret_cast<uint8_t*>(shiftF + 16);                // 4 copies x CB bytes
+    uint32_t* stage = reinterpret_cast<uint32_t*>(xs + 4 * (size_t)s.CB); // kStage: [rows][YPB/4] (+1) raw dwords
 
     // ---- once per workgroup: the fp32 bank is staged in LDS (in the still unused halo area; coalesced,
     // batched loads), then the per-kernel fixed-point scale and the digit table are computed out of LDS.
@@ -177,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             const float twoF = ldexpf(1.0f, shiftF[g]);  // exact power of two: wv * 2^F is exact
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int li = slot_index(st, qq, j);
+                const int li = slot_index<YPB>(st, qq, j);
                 if (li < nchunks) {
                     const int c = li / s.R, rho = li - c * s.R;
 #pragma unroll
@@ -206,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         int o[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int li = slot_index(st, qq, j);
+            const int li = slot_index<YPB>(st, qq, j);
             if (st < s.KS && li < nchunks) {
                 const int c = li / s.R, rho = li - c * s.R;
                 const int dz = rho / s.kx, dx = rho - dz * s.kx;
@@ -233,11 +283,14 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     int tile = blockIdx.x;
     if (tile >= s.ntiles) return;
     __syncthreads();  // the staged bank (aliasing the halo area) is dead from here on
-    halo_fill(xs, x, s, tile_coord(s, tile), tid, XP, rows);
+    halo_fill<YPB>(xs, x, s, tile_coord(s, tile), tid, XP, rows);
     __syncthreads();
 
     for (; tile < s.ntiles; tile += gridDim.x) {
         const TileCoord c = tile_coord(s, tile);
+        const int next = tile + gridDim.x;
+        const bool has_next = (next < s.ntiles) && !(s.dbg & 2);
+        if (kStage && has_next) halo_dma_issue<YPB>(stage, x, s, tile_coord(s, next), wave, lane, XP, rows);
         for (int round = wave; round < nrounds; round += kWaves) {
             const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
             const uint8_t* xb = xs + lanebase + (lz * XP + lx) * YPB;
@@ -370,19 +423,23 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 }
             }
         }
-        // [measured] prefetching the next halo into registers across the rounds (16 VGPRs) makes hipcc spill
-        // (the kernel wants > 400 registers at 2 waves/SIMD) and a 1-wave/SIMD build runs 1.9x slower: the halo
-        // refill therefore stays a synchronous phase (~5 us per tile, 13 % of the kernel at C2).
-        if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile
-        const int next = tile + gridDim.x;
-        if (next < s.ntiles && !(s.dbg & 2)) halo_fill(xs, x, s, tile_coord(s, next), tid, XP, rows);
+        // [measured] prefetching the next halo into REGISTERS across the rounds (16 VGPRs) makes hipcc spill (the
+        // kernel wants > 400 registers at 2 waves/SIMD) and a 1-wave/SIMD build runs 1.9x slower; LDS-DMA into a
+        // staging area (kStage) needs no registers.
+        if (kStage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile (and every DMA landed)
+        if (has_next) {
+            if (kStage) halo_expand<YPB>(xs, stage, s, tid, rows);
+            else halo_fill<YPB>(xs, x, s, tile_coord(s, next), tid, XP, rows);
+        }
         if (!(s.dbg & 4)) __syncthreads();
     }
 }
 
-size_t lds_bytes(const Shape& s) {
+size_t lds_bytes(const Shape& s, int ypb, bool stage) {
     const size_t KT = s.KS + kTablePad;
-    const size_t halo = 4 * (size_t)s.CB;
+    const size_t rows = (size_t)(s.TZ + s.kz - 1) * (s.TX + s.kx - 1);
+    const size_t halo = 4 * (size_t)s.CB + (stage ? rows * ypb + 16 : 0);
     const size_t staged_bank = (size_t)s.G * s.kz * s.kx * s.ky * sizeof(float);  // aliases the halo area
     return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
 }
@@ -418,39 +475,52 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     const int py = (ky - 1) / 2;
     s.PYA = (py + 3) & ~3;
     s.delta = s.PYA - py;
-    if (s.delta + 15 + 48 + 4 * s.C + 3 > YPB) return 1;
     s.nyt = (Y + TY - 1) / TY;
     const char* dbg = getenv("SN_CONV_I8_DBG");
     s.dbg = dbg ? atoi(dbg) : 0;
+    const char* nostage = getenv("SN_CONV_I8_NO_STAGE");
     const int cus = num_cus();
+    const int need = s.delta + 15 + 48 + 4 * s.C + 3;  // bytes of a halo row the reads can touch
+    // variants in order of preference: (row stride, LDS-DMA staging)
+    const int variants[][2] = {{80, 1}, {96, 0}};
     static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
-    bool found = false;
-    for (const auto& c : cand) {
-        s.TZ = c[0]; s.TX = c[1];
-        s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
-        s.ntiles = B * s.nzt * s.nxt * s.nyt;
-        s.CB = (s.TZ + kz - 1) * (s.TX + kx - 1) * YPB + kCopyPad;
-        if (lds_bytes(s) > (size_t)kMaxLds) continue;
-        found = true;
-        if (s.ntiles >= 4 * cus) break;
+    for (const auto& var : variants) {
+        const int ypb = var[0];
+        const bool stage = var[1] != 0;
+        if (need > ypb) continue;
+        if (stage && nostage && nostage[0] == '1') continue;
+        bool found = false;
+        for (const auto& c : cand) {
+            s.TZ = c[0]; s.TX = c[1];
+            s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
+            s.ntiles = B * s.nzt * s.nxt * s.nyt;
+            s.CB = (s.TZ + kz - 1) * (s.TX + kx - 1) * ypb + kCopyPad;
+            if (lds_bytes(s, ypb, stage) > (size_t)kMaxLds) continue;
+            found = true;
+            if (s.ntiles >= 4 * cus) break;
+        }
+        // staging only pays with the big tile (several rounds per wave between barriers); otherwise try the next
+        if (!found || (stage && (s.TZ != 8 || s.TX != 8))) continue;
+        const int grid = cus < s.ntiles ? cus : s.ntiles;
+        const size_t lds = lds_bytes(s, ypb, stage);
+#define SN_LAUNCH_I8(OT, YPBV, STG)                                                                              \
+    do {                                                                                                         \
+        auto kern = conv_occ_i8_kernel<OT, YPBV, STG>;                                                           \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) !=       \
+            hipSuccess)                                                                                          \
+            return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (OT*)act,         \
+                           (OT*)out);                                                                            \
+    } while (0)
+        if (out_dtype == SN_F32) {
+            if (stage) SN_LAUNCH_I8(float, 80, true); else SN_LAUNCH_I8(float, 96, false);
+        } else {
+            if (stage) SN_LAUNCH_I8(double, 80, true); else SN_LAUNCH_I8(double, 96, false);
+        }
+#undef SN_LAUNCH_I8
+        return check_launch("sn_conv_bank(i8)");
     }
-    if (!found) return 1;
-    int grid = cus < s.ntiles ? cus : s.ntiles;
-    const size_t lds = lds_bytes(s);
-    if (out_dtype == SN_F32) {
-        auto kern = conv_occ_i8_kernel<float>;
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess)
-            return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (float*)act,
-                           (float*)out);
-    } else {
-        auto kern = conv_occ_i8_kernel<double>;
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess)
-            return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (double*)act,
-                           (double*)out);
-    }
-    return check_launch("sn_conv_bank(i8)");
+    return 1;
 }
 
 }  // namespace sn

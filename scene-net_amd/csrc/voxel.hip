@@ -201,19 +201,29 @@ __global__ void desc_kernel(const double* __restrict__ box, int nparts, int nx, 
             lo[c] = bb[c];
             hi[c] = bb[3 + c];
         }
-    } else {  // ... reduced here (every thread redundantly: nparts is a few dozen)
+    } else {  // ... reduced here: one load per thread (all in flight at once), then a 64-lane shuffle tree
+        __shared__ double red[6];
         const double* bb = box + (size_t)b * nparts * 6;
+        if (threadIdx.x < 64) {  // lane l: slots l, l+64, ... of the [nparts][6] block; slot % 6 = component
+            for (int c = 0; c < 6; ++c) {
+                double v = (c < 3) ? DBL_MAX : -DBL_MAX;
+                for (int pp = threadIdx.x; pp < nparts; pp += 64) {
+                    const double u = bb[pp * 6 + c];
+                    v = (c < 3) ? fmin(v, u) : fmax(v, u);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double u = __shfl_xor(v, o, 64);
+                    v = (c < 3) ? fmin(v, u) : fmax(v, u);
+                }
+                if (threadIdx.x == 0) red[c] = v;
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            lo[c] = DBL_MAX;
-            hi[c] = -DBL_MAX;
-        }
-        for (int p = 0; p < nparts; ++p) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                lo[c] = fmin(lo[c], bb[p * 6 + c]);
-                hi[c] = fmax(hi[c], bb[p * 6 + 3 + c]);
-            }
+            lo[c] = red[c];
+            hi[c] = red[3 + c];
         }
         if (bbox_out && threadIdx.x < 3) {
             bbox_out[b * 6 + threadIdx.x] = lo[threadIdx.x];
