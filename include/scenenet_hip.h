@@ -159,8 +159,9 @@ int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_counts, int B,
 /* Occupancy-only form of the same step, for the fused pipeline: what SceneNet consumes is
  * ToFullDense(Voxelization(points)) (scripts/main.py:138-140), one bit per voxel.  Workgroups build the tile's
  * bitmap in LDS (no global atomics) and the result is expanded to occ / gt_occ [B,1,nz,nx,ny] of out_dtype
- * (SN_U8 or SN_F32); gt_occ nullable.  Needs nx*ny*nz % 32 == 0 and the bitmap(s) to fit 64 KiB of LDS
- * (64^3 with or without gt_occ); otherwise SN_ERR_UNSUPPORTED -> use sn_voxel_scatter + sn_voxel_finalize.
+ * (SN_U8 or SN_F32); gt_occ nullable.  Needs nx*ny*nz % 32 == 0 and the bitmap(s) of one of <= SN_OCC_PARTS
+ * z-slabs to fit 64 KiB of LDS (64^3: one slab; 128^3: 4 slabs, 8 with gt_occ); otherwise SN_ERR_UNSUPPORTED ->
+ * use sn_voxel_scatter + sn_voxel_finalize.
  *   bits_ws     scratch, SN_OCC_WS_WORDS(B, nx*ny*nz, planes) uint32 (planes = 2 with gt_occ, else 1)
  *   flags       (nullable) [B] i32 out: 1 = the tile could not be proven free of a fully occupied y column
  *               (where ToFullDense(density) != (count > 0)); such tiles are recomputed exactly (counts by

@@ -212,9 +212,18 @@ def voxel_finalize(counts, towers, want_density=False, want_gt=False, want_occ=T
 
 
 def occupancy_supported(n_xyz: Sequence[int], planes: int) -> bool:
+    """mirrors sn_voxel_occupancy's z-slab rule: some power-of-two slab count <= SN_OCC_PARTS fits the LDS bitmap."""
     nx, ny, nz = (int(v) for v in n_xyz)
     V = nx * ny * nz
-    return V % 32 == 0 and (V // 32) * planes <= OCC_MAX_WORDS
+    if V % 32:
+        return False
+    sl = 1
+    while sl <= SN_OCC_PARTS:
+        if nz % sl == 0 and (V // 32) % sl == 0 and ((nz // sl) * nx * ny) % 32 == 0 \
+                and (V // 32 // sl) * planes <= OCC_MAX_WORDS:
+            return True
+        sl *= 2
+    return False
 
 
 def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[float] = (), want_gt_occ: bool = False,

@@ -344,14 +344,17 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const double* __restr
 }
 
 // ---------------------------------------------------------------- occupancy bitmap (LDS atomics)
-// grid (kOccParts, B).  LDS: edge table, then `words` of occupancy bits, then (optionally) `words`
-// of tower bits.  part p of tile b writes bits_ws[(b*kOccParts + p) * planes * words ...].
+// grid (parts * slabs, B).  Workgroup (part, slab) streams part's share of the tile's points and owns the bits of
+// z-slab `slab` (bitmaps larger than the LDS budget -- 128^3 -- are split into slabs; every slab's workgroup then
+// re-reads the points, which come from L2 / Infinity Cache).  LDS: edge table, then `swords` words of occupancy
+// bits, then (optionally) `swords` of tower bits.  Part p writes bits_ws[(b*parts + p) * planes * words ...].
 template <bool kAligned>
 __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* __restrict__ pts,
                                                                   const double* __restrict__ labels,
                                                                   const int64_t* __restrict__ offsets,
                                                                   const double* __restrict__ desc, int nx, int ny,
-                                                                  int nz, int words, int planes, KeepLabels keep,
+                                                                  int nz, int words, int planes, int parts,
+                                                                  int slabs, KeepLabels keep,
                                                                   uint32_t* __restrict__ bits_ws,
                                                                   int32_t* __restrict__ dropped_parts,
                                                                   int32_t* __restrict__ flags) {
@@ -363,37 +366,44 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
     uint32_t* bits = reinterpret_cast<uint32_t*>(smem + ((ne + 1) & ~1));  // 16-byte aligned
     const int b = blockIdx.y;
     const double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
-    for (int i = threadIdx.x; i < words * planes; i += kOccThreads) bits[i] = 0u;
+    const int part = blockIdx.x / slabs, slab = blockIdx.x - part * slabs;
+    const int swords = words / slabs;
+    const int f_lo = slab * swords * 32, f_hi = f_lo + swords * 32;  // flat voxel range of this slab
+    for (int i = threadIdx.x; i < swords * planes; i += kOccThreads) bits[i] = 0u;
     load_edges(edges, d, ne, kOccThreads);  // ends with __syncthreads()
     Binner bin;
     bin.init(edges, d, nx, ny, nz);
     const bool want_tower = (planes == 2);
     int dropped = 0;
-    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kOccThreads + threadIdx.x,
-                             (long)gridDim.x * kOccThreads, [&](double x, double y, double z, long i) {
+    for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)part * kOccThreads + threadIdx.x,
+                             (long)parts * kOccThreads, [&](double x, double y, double z, long i) {
                                  const int f = bin.flat(x, y, z);
-                                 if (f < 0) { ++dropped; return; }
-                                 atomicOr(&bits[f >> 5], 1u << (f & 31));
+                                 if (f < 0) { dropped += (slab == 0); return; }
+                                 if (f < f_lo || f >= f_hi) return;
+                                 const int g = f - f_lo;
+                                 atomicOr(&bits[g >> 5], 1u << (g & 31));
                                  if (want_tower && is_kept(labels[i], keep))
-                                     atomicOr(&bits[words + (f >> 5)], 1u << (f & 31));
+                                     atomicOr(&bits[swords + (g >> 5)], 1u << (g & 31));
                              });
     __syncthreads();
-    uint32_t* out = bits_ws + ((size_t)b * kOccParts + blockIdx.x) * (size_t)planes * words;
-    for (int i = threadIdx.x; i < words * planes; i += kOccThreads) out[i] = bits[i];
+    uint32_t* out = bits_ws + ((size_t)b * parts + part) * (size_t)planes * words + (size_t)slab * swords;
+    for (int i = threadIdx.x; i < swords; i += kOccThreads) {
+        out[i] = bits[i];
+        if (want_tower) out[words + i] = bits[swords + i];
+    }
     if (dropped) atomicAdd(&dropped_blk, dropped);  // LDS
     __syncthreads();
-    if (threadIdx.x == 0) {
-        dropped_parts[b * kOccParts + blockIdx.x] = dropped_blk;
-        if (flags && blockIdx.x == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
+    if (threadIdx.x == 0 && slab == 0) {
+        dropped_parts[b * parts + part] = dropped_blk;
+        if (flags && part == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
     }
 }
 
-// OR of the kOccParts partial bitmaps of one tile (plane 0 = occupancy, 1 = towers), word w
-__device__ __forceinline__ uint32_t merged_word(const uint32_t* __restrict__ src, int planes, int words, int plane,
-                                                long w) {
+// OR of the `parts` partial bitmaps of one tile (plane 0 = occupancy, 1 = towers), word w
+__device__ __forceinline__ uint32_t merged_word(const uint32_t* __restrict__ src, int parts, int planes, int words,
+                                                int plane, long w) {
     uint32_t m = 0u;
-#pragma unroll
-    for (int p = 0; p < kOccParts; ++p) m |= src[((size_t)p * planes + plane) * words + w];
+    for (int p = 0; p < parts; ++p) m |= src[((size_t)p * planes + plane) * words + w];
     return m;
 }
 
@@ -424,7 +434,7 @@ __device__ __forceinline__ void expand_word<float>(uint32_t m, float* __restrict
 // flag was raised by occ_partial_kernel and is cleared here by whoever finds an empty row.
 template <typename OT>
 __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* __restrict__ bits_ws, int words,
-                                                                int planes, int rows, int ny, size_t V,
+                                                                int planes, int parts, int rows, int ny, size_t V,
                                                                 OT* __restrict__ occ, OT* __restrict__ gt_occ,
                                                                 int32_t* __restrict__ flags,
                                                                 const int32_t* __restrict__ dropped_parts,
@@ -432,14 +442,14 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
     const int b = blockIdx.y;
     if (dropped && blockIdx.x == 0 && threadIdx.x == 0) {
         int t = 0;
-        for (int p = 0; p < kOccParts; ++p) t += dropped_parts[b * kOccParts + p];
+        for (int p = 0; p < parts; ++p) t += dropped_parts[b * parts + p];
         dropped[b] = t;
     }
-    const uint32_t* src = bits_ws + (size_t)b * kOccParts * planes * words;
+    const uint32_t* src = bits_ws + (size_t)b * parts * planes * words;
     const int gtid = blockIdx.x * kThreads + threadIdx.x, gstride = gridDim.x * kThreads;
     for (int w = gtid; w < words; w += gstride) {
-        expand_word<OT>(merged_word(src, planes, words, 0, w), occ + (size_t)b * V + (size_t)w * 32);
-        if (gt_occ) expand_word<OT>(merged_word(src, planes, words, 1, w), gt_occ + (size_t)b * V + (size_t)w * 32);
+        expand_word<OT>(merged_word(src, parts, planes, words, 0, w), occ + (size_t)b * V + (size_t)w * 32);
+        if (gt_occ) expand_word<OT>(merged_word(src, parts, planes, words, 1, w), gt_occ + (size_t)b * V + (size_t)w * 32);
     }
     if (!flags) return;
     // row r owns bits [r*ny, (r+1)*ny)
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
         const long lo = (long)r * ny, hi = lo + ny;
         uint32_t any = 0u;
         for (long w = lo >> 5; w <= (hi - 1) >> 5; ++w) {
-            uint32_t m = merged_word(src, planes, words, 0, w);
+            uint32_t m = merged_word(src, parts, planes, words, 0, w);
             const long wlo = w << 5;
             if (lo > wlo) m &= ~0u << (lo - wlo);
             if (hi < wlo + 32) m &= ~0u >> (wlo + 32 - hi);
@@ -765,10 +775,20 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
         return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_occupancy: n_keep=%d outside [0,%d] or null list", n_keep,
                         kMaxKeep);
     const size_t V = (size_t)nx * ny * nz;
-    if (V % 32 != 0 || (V / 32) * planes > (size_t)kMaxOccWords)
+    // z-slabs: the bitmap(s) of one slab must fit the 64 KiB LDS budget and start on a word boundary
+    int slabs = 0;
+    if (V % 32 == 0)
+        for (int sl = 1; sl <= kOccParts; sl *= 2)
+            if (nz % sl == 0 && (V / 32) % sl == 0 && ((size_t)nz / sl) * nx * ny % 32 == 0 &&
+                (V / 32 / sl) * planes <= (size_t)kMaxOccWords) {
+                slabs = sl;
+                break;
+            }
+    if (!slabs)
         return sn::fail(SN_ERR_UNSUPPORTED,
-                        "sn_voxel_occupancy: %zu voxels x %d planes do not fit the 64 KiB LDS bitmap "
-                        "(use sn_voxel_scatter + sn_voxel_finalize)", V, planes);
+                        "sn_voxel_occupancy: %zu voxels x %d planes do not fit the LDS bitmap in <= %d z-slabs "
+                        "(use sn_voxel_scatter + sn_voxel_finalize)", V, planes, kOccParts);
+    const int parts = kOccParts / slabs;
     if (gt_occ && flags && counts_ws && !towers_ws)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: the counting fallback needs towers_ws for gt_occ");
     const int words = (int)(V / 32);
@@ -776,25 +796,26 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
     hipStream_t s = sn::as_stream(stream);
     // per-part dropped counts live behind the partial bitmaps in bits_ws (SN_OCC_WS_WORDS accounts for them)
     int32_t* dropped_parts = reinterpret_cast<int32_t*>(bits_ws + (size_t)B * kOccParts * planes * words);
-    const size_t lds1 = (size_t)((ne + 1) & ~1) * sizeof(double) + (size_t)words * planes * sizeof(uint32_t);
+    const size_t lds1 =
+        (size_t)((ne + 1) & ~1) * sizeof(double) + (size_t)(words / slabs) * planes * sizeof(uint32_t);
     const bool al = aligned16(pts) && (!labels || aligned16(labels));
     {
         auto kern = al ? occ_partial_kernel<true> : occ_partial_kernel<false>;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
             hipSuccess)
             return sn::check_launch("sn_voxel_occupancy(hipFuncSetAttribute)");
-        hipLaunchKernelGGL(kern, dim3(kOccParts, B), dim3(kOccThreads), lds1, s, pts, labels, offsets, desc, nx, ny,
-                           nz, words, planes, keep, bits_ws, dropped_parts, flags);
+        hipLaunchKernelGGL(kern, dim3(parts * slabs, B), dim3(kOccThreads), lds1, s, pts, labels, offsets, desc, nx,
+                           ny, nz, words, planes, parts, slabs, keep, bits_ws, dropped_parts, flags);
     }
     const int rows = nz * nx;
     int C = (words + kThreads - 1) / kThreads;
     if (C > blocks_per_tile(B, 2048)) C = blocks_per_tile(B, 2048);
     if (out_dtype == SN_U8)
         hipLaunchKernelGGL(occ_finalize_kernel<uint8_t>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes,
-                           rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped);
+                           parts, rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped);
     else
-        hipLaunchKernelGGL(occ_finalize_kernel<float>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes, rows,
-                           ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped);
+        hipLaunchKernelGGL(occ_finalize_kernel<float>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes, parts,
+                           rows, ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped);
     // flagged tiles (a y column might be full): redone exactly by one gated launch
     if (flags && counts_ws) {
         const size_t lds3 = (size_t)ne * sizeof(double) + (size_t)ny * sizeof(int);

@@ -51,8 +51,8 @@ def test_argument_checks_need_no_gpu():
     assert lib.sn_conv_bank(p, 0, p, p, 0, 8, 8, 8, 4, 3, 3, 3, p, p, 0, None) == -1  # B = 0
     assert lib.sn_voxel_scatter(p, None, p, 1, p, 4, 4, 4, p, p, None, 0, None, None) == -1  # towers w/o labels
     assert lib.sn_voxel_scatter(p, p, p, 1, p, 4, 4, 4, p, p, None, 3, None, None) == -2  # keep list missing
-    # occupancy form: 128^3 bits do not fit the LDS bitmap -> caller must take the counting kernels
-    assert lib.sn_voxel_occupancy(p, None, p, 1, p, 128, 128, 128, None, 0, p, p, None, 2, None, None, None, None,
+    # occupancy form: 512^3 bits do not fit the LDS bitmap even in 16 z-slabs -> caller must take the counting kernels
+    assert lib.sn_voxel_occupancy(p, None, p, 1, p, 512, 512, 512, None, 0, p, p, None, 2, None, None, None, None,
                                   None) == -2
     assert b"LDS bitmap" in lib.sn_last_error()
     assert lib.sn_voxel_occupancy(p, None, p, 1, p, 64, 64, 64, None, 0, p, p, None, 1, None, None, None, None,

@@ -157,10 +157,17 @@ def test_full_size_c2_batch_properties(hip_device):
     assert int(g1.dropped.sum().item()) == 0
     for b in range(B):
         _check_tile(g1, b, tiles[b], labels[b], (64, 64, 64), [15])
-    # 128^3 (C3 grid) on the same clouds
-    g3 = sna.voxelize_batch(batch, (128, 128, 128), [15], want_occ=True)
+    # 128^3 (C3 grid) on the same clouds: the LDS-bitmap path in 4 z-slabs (8 with the tower plane)
+    g3 = sna.voxelize_batch(batch, (128, 128, 128), [15], want_occ=True, occ_dtype=torch.bool)
+    g5 = sna.voxelize_batch(batch, (128, 128, 128), [15], want_occ=True, want_gt_occ=True)
+    assert g3.counts is None and g5.counts is None and int(g3.flags.sum().item()) == 0
     for b in (0, 17, 31):
         _check_tile(g3, b, tiles[b], labels[b], (128, 128, 128), [15])
+        _check_tile(g5, b, tiles[b], labels[b], (128, 128, 128), [15])
+    # non-cubic grid whose bitmap needs 2 slabs
+    g6 = sna.voxelize_batch(batch, (64, 128, 128), want_occ=True)
+    assert g6.counts is None
+    _check_tile(g6, 5, tiles[5], None, (64, 128, 128), None)
 
 
 def test_unaligned_point_buffer(hip_device):
