@@ -28,6 +28,9 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// torch.relu keeps NaN (fmaxf(NaN, 0) would return 0)
+__device__ __forceinline__ float relu_nan(float v) { return (v > 0.0f || v != v) ? v : 0.0f; }
+
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int TY = 64;   // y extent of a workgroup tile
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
                         OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
                         float t = sv;
                         if (s.head & 1) t += (float)*o;  // kernels of earlier 16-groups (G > 16)
-                        *o = (OT)((s.head & 2) ? fmaxf(tanhf(t), 0.0f) : t);
+                        *o = (OT)((s.head & 2) ? relu_nan(tanhf(t)) : t);
                     }
                 }
             }

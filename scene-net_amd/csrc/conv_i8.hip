@@ -27,6 +27,9 @@ namespace {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
+// torch.relu keeps NaN (fmaxf(NaN, 0) would return 0)
+__device__ __forceinline__ float relu_nan(float v) { return (v > 0.0f || v != v) ? v : 0.0f; }
+
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int TY = 64;        // y extent of a workgroup tile
@@ -205,15 +208,23 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     for (int g = wave; g < 16; g += kWaves) {
         float m = 0.0f;
         if (g < s.G)
-            for (int t = lane; t < ntaps; t += 64) m = fmaxf(m, fabsf(bank_s[g * ntaps + t]));
+            for (int t = lane; t < ntaps; t += 64) {
+                const float a = fabsf(bank_s[g * ntaps + t]);
+                m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);  // NaN / inf weight poisons the kernel
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        for (int o = 32; o > 0; o >>= 1) {
+            const float u = __shfl_xor(m, o, 64);
+            m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
+        }
         if (lane == 0) {
             int e = 0;
             if (m > 0.0f) (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)  ->  m <= 2^e
             const int F = 22 - e;
             shiftF[g] = F;
-            scale[g] = ldexpf(1.0f, -F);
+            // fixed point cannot carry a NaN / inf weight: such a kernel's whole response is NaN, as it is in
+            // conv3d (0 * NaN = NaN at every voxel)
+            scale[g] = (m != m) ? m : ldexpf(1.0f, -F);
         }
     }
     __syncthreads();
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                         OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
                         float t = sv;
                         if (s.head & 1) t += (float)*o;
-                        *o = (OT)((s.head & 2) ? fmaxf(tanhf(t), 0.0f) : t);
+                        *o = (OT)((s.head & 2) ? relu_nan(tanhf(t)) : t);
                     }
                 }
             }

@@ -267,3 +267,20 @@ def test_more_than_16_kernels(hip_device, G):
     model = sna.SceneNet({"cy": 8, "cone": 6, "neg": 6}, (9, 5, 5)).to(hip_device)
     y = model(occ.to(hip_device))
     assert y.shape == occ.shape and y.min().item() >= 0 and y.max().item() <= 1  # fp32 tanh saturates to 1.0
+
+
+def test_non_finite_weights_propagate_like_conv3d(hip_device):
+    """A NaN weight makes that kernel's whole response NaN (0 * NaN = NaN at every voxel) and, through the head,
+    the output; torch.relu keeps NaN.  Holds for the fp32 and the int8 kernel."""
+    torch.manual_seed(4)
+    occ = torch.rand(1, 1, 10, 10, 16) < 0.3
+    bank = _rand_bank(4, (3, 3, 3), 1, "cpu")
+    bank[2, 1, 1, 1] = float("nan")
+    lam = torch.tensor([0.2, 0.3, 0.25, 0.25])
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    assert torch.isnan(ref_act[:, 2]).all() and not torch.isnan(ref_act[:, [0, 1, 3]]).any()
+    for x in (occ, occ.float()):
+        act, out = _hip.conv_bank(x.to(hip_device), bank.to(hip_device).contiguous(), lam.to(hip_device),
+                                  want_act=True, want_out=True)
+        assert torch.isnan(act[:, 2]).all() and not torch.isnan(act[:, [0, 1, 3]]).any()
+        assert torch.isnan(out).all()
