@@ -65,6 +65,13 @@ const char* sn_last_error(void);
 /* Number of gfx950 devices visible (0 when none); never throws. */
 int sn_device_count(void);
 
+/* Process-wide options (default 0).
+ *   "conv_skip_empty_tiles": sn_conv_bank on SN_OCC8 input skips the MFMA steps of workgroup tiles whose halo holds
+ *       no set voxel (their response is exactly 0 for every kernel).  Output unchanged; run time becomes data
+ *       dependent, so benchmarks quote it separately from the dense figure. */
+int sn_set_option(const char* name, int value);
+int sn_get_option(const char* name);
+
 /* ------------------------------------------------------------------------- *
  * K2  GENEO bank builder
  * replaces: GENEO_Layer.compute_kernel (core/models/SCENE_Net.py:103-106) over

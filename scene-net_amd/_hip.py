@@ -27,6 +27,8 @@ SYMBOLS = {
     "sn_version": (c_int, []),
     "sn_last_error": (c_char_p, []),
     "sn_device_count": (c_int, []),
+    "sn_set_option": (c_int, [c_char_p, _I]),
+    "sn_get_option": (c_int, [c_char_p]),
     "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
@@ -75,6 +77,15 @@ def _check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().sn_last_error()
         raise HipLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide library option (include/scenenet_hip.h: sn_set_option)."""
+    _check(load().sn_set_option(name.encode(), int(value)), "sn_set_option")
+
+
+def get_option(name: str) -> int:
+    return int(load().sn_get_option(name.encode()))
 
 
 def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str = "tensor") -> Optional[int]:

@@ -2,12 +2,30 @@
 #include "common.h"
 #include <cstring>
 
+#include <atomic>
+
 namespace sn {
 char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+static std::atomic<int> g_skip_empty{0};
+int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
 }  // namespace sn
+
+extern "C" int sn_set_option(const char* name, int value) {
+    if (!name) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: null name");
+    if (strcmp(name, "conv_skip_empty_tiles") == 0) {
+        sn::g_skip_empty.store(value ? 1 : 0, std::memory_order_relaxed);
+        return SN_OK;
+    }
+    return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: unknown option '%s'", name);
+}
+
+extern "C" int sn_get_option(const char* name) {
+    if (name && strcmp(name, "conv_skip_empty_tiles") == 0) return sn::option_conv_skip_empty_tiles();
+    return -1;
+}
 
 extern "C" int sn_version(void) { return 100; }
 

@@ -25,4 +25,6 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
+
 }  // namespace sn

@@ -51,6 +51,8 @@ struct Shape {
     int PYA, delta; // halo origin = y0 - PYA (PYA = roundup(py, 4)), delta = PYA - py
     int CB;         // bytes between the shifted copies
     int Gtot, g0, head;  // kernel group of a larger bank: act channel stride/offset; head bits (see conv.hip)
+    int perm;       // tile order multiplier, coprime to ntiles
+    int skip_empty; // opt-in: skip the MFMA steps of halo tiles without a set voxel (result is exactly 0)
     int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier
 };
 
@@ -58,8 +60,13 @@ struct TileCoord {
     int b, z0, x0, y0;
 };
 
+// Workgroup w handles virtual tiles w, w+grid, ...; virtual tile t is actual tile (t * perm) mod ntiles, perm coprime
+// to ntiles.  With the plain order a workgroup's tiles all share (x-tile, z-tile) residues, i.e. the same kind of
+// region of every sample -- fine for dense work, but with conv_skip_empty_tiles some workgroups would get only empty
+// tiles and others none.
 __device__ __forceinline__ TileCoord tile_coord(const Shape& s, int tile) {
     TileCoord c;
+    tile = (int)(((long long)tile * s.perm) % s.ntiles);
     c.y0 = (tile % s.nyt) * TY; tile /= s.nyt;
     c.x0 = (tile % s.nxt) * s.TX; tile /= s.nxt;
     c.z0 = (tile % s.nzt) * s.TZ; tile /= s.nzt;
@@ -84,8 +91,9 @@ __device__ __forceinline__ int slot_index(int s, int q, int j) {
 // halo tile: copies[k][r][i] (bytes), copy k = tile shifted by k bytes.  Global rows are read as aligned
 // dwords (Y % 4 == 0, origin y0 - PYA is a multiple of 4): out-of-grid dwords come from a zero word.
 template <int YPB>
-__device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_t* __restrict__ x, const Shape& s,
-                                          const TileCoord& c, int tid, int XP, int rows) {
+__device__ __forceinline__ uint32_t halo_fill(uint8_t* __restrict__ xs, const uint8_t* __restrict__ x,
+                                              const Shape& s, const TileCoord& c, int tid, int XP, int rows) {
+    uint32_t seen = 0u;  // OR of every dword this thread staged
     constexpr int DW = YPB / 4;
     const int total = rows * DW;
     constexpr int kBatch = 11;  // (16*16 rows x 24 dwords) / 512 threads = 10.5: one batch, one latency
@@ -111,6 +119,7 @@ __device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_
         for (int u = 0; u < kBatch; ++u) {
             const int idx = base + u * kThreads;
             if (idx < total) {
+                seen |= lo[u];
                 uint32_t* d = reinterpret_cast<uint32_t*>(xs) + idx;  // dword idx of copy 0
                 d[0] = lo[u];
                 d[(s.CB >> 2)] = __builtin_amdgcn_alignbyte(hi[u], lo[u], 1);
@@ -119,6 +128,7 @@ __device__ __forceinline__ void halo_fill(uint8_t* __restrict__ xs, const uint8_
             }
         }
     }
+    return seen;
 }
 
 // LDS-DMA of the next tile's raw rows: item idx = (row r, dword i) lands at stage[idx]; a wave-instruction
@@ -146,13 +156,15 @@ __device__ __forceinline__ void halo_dma_issue(uint32_t* __restrict__ stage, con
 
 // staging -> the four byte-shifted copies (pure LDS traffic)
 template <int YPB>
-__device__ __forceinline__ void halo_expand(uint8_t* __restrict__ xs, const uint32_t* __restrict__ stage,
-                                            const Shape& s, int tid, int rows) {
+__device__ __forceinline__ uint32_t halo_expand(uint8_t* __restrict__ xs, const uint32_t* __restrict__ stage,
+                                                const Shape& s, int tid, int rows) {
     constexpr int DW = YPB / 4;
     const int total = rows * DW;
     const int cs = s.CB >> 2;
+    uint32_t seen = 0u;
     for (int idx = tid; idx < total; idx += kThreads) {
         const uint32_t lo = stage[idx];
+        seen |= lo;
         const uint32_t hi = stage[idx + 1];  // last dword of a row: its shifted copies are never read back
         uint32_t* d = reinterpret_cast<uint32_t*>(xs) + idx;
         d[0] = lo;
@@ -160,13 +172,15 @@ __device__ __forceinline__ void halo_expand(uint8_t* __restrict__ xs, const uint
         d[2 * cs] = __builtin_amdgcn_alignbyte(hi, lo, 2);
         d[3 * cs] = __builtin_amdgcn_alignbyte(hi, lo, 3);
     }
+    return seen;
 }
 
 template <typename OT, int YPB, bool kStage>
 __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __restrict__ x,
                                                                const float* __restrict__ bank,
                                                                const float* __restrict__ lambdas, Shape s,
-                                                               OT* __restrict__ act, OT* __restrict__ out) {
+                                                               int* __restrict__ ticket, OT* __restrict__ act,
+                                                               OT* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -181,7 +195,9 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     int4* coff = reinterpret_cast<int4*>(lds + (size_t)KT * 3 * 64 * 16); // [KT][4] x 16 B
     float* scale = reinterpret_cast<float*>(coff + KT * 4);               // [16]   2^-F_g
     int* shiftF = reinterpret_cast<int*>(scale + 16);                     // [16]   F_g
-    uint8_t* xs = reinterpret_cast<uint8_t*>(shiftF + 16);                // 4 copies x CB bytes
+    int* wseen = shiftF + 16;                                             // [8]    per wave: halo tile has a set voxel
+    int* tnext = wseen + 8;                                               // [1]    dynamic scheduling: next tile
+    uint8_t* xs = reinterpret_cast<uint8_t*>(wseen + 16);                 // 4 copies x CB bytes
     uint32_t* stage = reinterpret_cast<uint32_t*>(xs + 4 * (size_t)s.CB); // kStage: [rows][YPB/4] (+1) raw dwords
 
     // ---- once per workgroup: the fp32 bank is staged in LDS (in the still unused halo area; coalesced,
@@ -291,17 +307,35 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     const int nd = n + s.delta;
     const int lanebase = (nd & 3) * s.CB + (nd & ~3);
 
+    // Tile order: static (w, w+grid, ...) or, with a ticket counter (conv_skip_empty_tiles: tiles then cost very
+    // different amounts), dynamic -- one thread draws the ticket of the tile after next while the rounds run.
     int tile = blockIdx.x;
     if (tile >= s.ntiles) return;
+    if (ticket && tid == 0) *tnext = gridDim.x + atomicAdd(ticket, 1);
     __syncthreads();  // the staged bank (aliasing the halo area) is dead from here on
-    halo_fill<YPB>(xs, x, s, tile_coord(s, tile), tid, XP, rows);
+    {
+        const uint32_t seen = halo_fill<YPB>(xs, x, s, tile_coord(s, tile), tid, XP, rows);
+        const bool w = __ballot(seen != 0u) != 0ull;
+        if (lane == 0) wseen[wave] = w;
+    }
     __syncthreads();
 
-    for (; tile < s.ntiles; tile += gridDim.x) {
+    while (tile < s.ntiles) {
         const TileCoord c = tile_coord(s, tile);
-        const int next = tile + gridDim.x;
+        const int next = ticket ? *tnext : tile + (int)gridDim.x;
         const bool has_next = (next < s.ntiles) && !(s.dbg & 2);
         if (kStage && has_next) halo_dma_issue<YPB>(stage, x, s, tile_coord(s, next), wave, lane, XP, rows);
+        int after_next = 0;
+        if (ticket && tid == 0) after_next = gridDim.x + atomicAdd(ticket, 1);
+        // opt-in (sn_set_option "conv_skip_empty_tiles"): a halo tile without a single set voxel convolves to
+        // exactly 0 for every kernel -- its MFMA steps are skipped, the epilogue still writes the (zero) result
+        int ks_run = s.KS;
+        if (s.skip_empty) {
+            int seen = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) seen |= wseen[w];
+            if (!seen) ks_run = 0;
+        }
         for (int round = wave; round < nrounds; round += kWaves) {
             const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
             const uint8_t* xb = xs + lanebase + (lz * XP + lx) * YPB;
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     gather_pair(GC, X, GP);                  \
     mma_pair(W, X, MP);                      \
     __builtin_amdgcn_sched_barrier(0);
-            for (int st = 0; st < s.KS; st += 2) {
+            for (int st = 0; st < ks_run; st += 2) {
                 load_w(st + 1, wb);
                 cb = coff[(st + 1) * 4 + q];
                 SN_SB(ca, 2, wa, 0)
@@ -440,10 +474,14 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         if (kStage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
         if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile (and every DMA landed)
         if (has_next) {
-            if (kStage) halo_expand<YPB>(xs, stage, s, tid, rows);
-            else halo_fill<YPB>(xs, x, s, tile_coord(s, next), tid, XP, rows);
+            const uint32_t seen = kStage ? halo_expand<YPB>(xs, stage, s, tid, rows)
+                                         : halo_fill<YPB>(xs, x, s, tile_coord(s, next), tid, XP, rows);
+            const bool w = __ballot(seen != 0u) != 0ull;
+            if (lane == 0) wseen[wave] = w;
         }
+        if (ticket && tid == 0) *tnext = after_next;  // everybody read the old value before the barrier above
         if (!(s.dbg & 4)) __syncthreads();
+        tile = next;
     }
 }
 
@@ -452,7 +490,7 @@ size_t lds_bytes(const Shape& s, int ypb, bool stage) {
     const size_t rows = (size_t)(s.TZ + s.kz - 1) * (s.TX + s.kx - 1);
     const size_t halo = 4 * (size_t)s.CB + (stage ? rows * ypb + 16 : 0);
     const size_t staged_bank = (size_t)s.G * s.kz * s.kx * s.ky * sizeof(float);  // aliases the halo area
-    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
+    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
 }
 
 int num_cus() {
@@ -489,6 +527,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     s.nyt = (Y + TY - 1) / TY;
     const char* dbg = getenv("SN_CONV_I8_DBG");
     s.dbg = dbg ? atoi(dbg) : 0;
+    s.skip_empty = sn::option_conv_skip_empty_tiles();
     const char* nostage = getenv("SN_CONV_I8_NO_STAGE");
     const int cus = num_cus();
     const int need = s.delta + 15 + 48 + 4 * s.C + 3;  // bytes of a halo row the reads can touch
@@ -514,14 +553,26 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
         if (!found || (stage && (s.TZ != 8 || s.TX != 8))) continue;
         const int grid = cus < s.ntiles ? cus : s.ntiles;
         const size_t lds = lds_bytes(s, ypb, stage);
+        s.perm = 1;
+        for (int cand_p : {97, 101, 103, 107, 109, 113, 127, 131})
+            if (s.ntiles % cand_p != 0) { s.perm = cand_p; break; }  // primes: coprime unless they divide ntiles
+        // dynamic tile scheduling when tile costs are data dependent: a stream-ordered 4-byte ticket counter
+        int* ticket = nullptr;
+        if (s.skip_empty && s.ntiles > grid) {
+            if (hipMallocAsync((void**)&ticket, sizeof(int), stream) != hipSuccess ||
+                hipMemsetAsync(ticket, 0, sizeof(int), stream) != hipSuccess) {
+                (void)hipGetLastError();
+                ticket = nullptr;  // static order still gives the right answer
+            }
+        }
 #define SN_LAUNCH_I8(OT, YPBV, STG)                                                                              \
     do {                                                                                                         \
         auto kern = conv_occ_i8_kernel<OT, YPBV, STG>;                                                           \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) !=       \
             hipSuccess)                                                                                          \
             return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (OT*)act,         \
-                           (OT*)out);                                                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, ticket,           \
+                           (OT*)act, (OT*)out);                                                                  \
     } while (0)
         if (out_dtype == SN_F32) {
             if (stage) SN_LAUNCH_I8(float, 80, true); else SN_LAUNCH_I8(float, 96, false);
@@ -529,6 +580,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
             if (stage) SN_LAUNCH_I8(double, 80, true); else SN_LAUNCH_I8(double, 96, false);
         }
 #undef SN_LAUNCH_I8
+        if (ticket) (void)hipFreeAsync(ticket, stream);
         return check_launch("sn_conv_bank(i8)");
     }
     return 1;

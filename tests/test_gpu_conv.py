@@ -284,3 +284,27 @@ def test_non_finite_weights_propagate_like_conv3d(hip_device):
                                   want_act=True, want_out=True)
         assert torch.isnan(act[:, 2]).all() and not torch.isnan(act[:, [0, 1, 3]]).any()
         assert torch.isnan(out).all()
+
+
+def test_skip_empty_tiles_option_changes_nothing_but_time(hip_device):
+    """conv_skip_empty_tiles: bit-identical output on a LiDAR-like batch with large empty regions."""
+    from scene_net_amd.synthetic import synthetic_bank_spec, synthetic_tile
+    specs, names, lambdas, last = synthetic_bank_spec()
+    bank = go.geneo_bank(specs, (9, 9, 9))[:, 0].float().to(hip_device).contiguous()
+    lam = go.effective_lambdas(lambdas, last, names).to(hip_device)
+    tiles = [synthetic_tile(t, 50_000)[0] for t in range(4)]
+    occ = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles, device=hip_device), (64, 64, 64),
+                             occ_dtype=torch.bool).occ
+    assert _hip.get_option("conv_skip_empty_tiles") == 0
+    act0, out0 = _hip.conv_bank(occ, bank, lam, want_act=True, want_out=True)
+    _hip.set_option("conv_skip_empty_tiles", 1)
+    try:
+        act1, out1 = _hip.conv_bank(occ, bank, lam, want_act=True, want_out=True)
+        empty = torch.zeros_like(occ)
+        a2, o2 = _hip.conv_bank(empty, bank, lam, want_act=True, want_out=True)
+    finally:
+        _hip.set_option("conv_skip_empty_tiles", 0)
+    assert torch.equal(act0, act1) and torch.equal(out0, out1)
+    assert a2.abs().max().item() == 0 and o2.abs().max().item() == 0
+    with pytest.raises(sna.HipLibraryError):
+        _hip.set_option("no_such_option", 1)
