@@ -211,6 +211,45 @@ int sn_conv_corr_blocks(int B, int Z, int X, int Y);
 int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
                       const float* dW, float* dparams, sn_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * K5  training criterion on the prediction grid
+ * replaces: WeightedMSE.forward + get_weight_target/get_dens_target (core/criterions/w_mse.py:114-151),
+ *           FocalTverskyLoss.forward / TverskyLoss.forward (core/criterions/tversky_loss.py:81-95, :35-51),
+ *           BinaryDiceLoss.forward, p = 2, reduction 'mean' (core/criterions/dice_loss.py:33-51),
+ *           summed as in GENEO_Loss / GENEO_Dice_Loss / GENEO_Tversky_Loss.forward (geneo_loss.py:72-81, :131-161).
+ * The scalar penalties over the ~50 parameters (cvx_loss, positive_regularizer, geneo_loss.py:36-70) stay on the
+ * host side.
+ *
+ * Everything the criterion needs from the B*n_per elements is a handful of sums, taken in ONE pass over
+ * (pred, gt): per weight bin k (bin = argmin_k |gt - ranges[k]|, first minimum, w_mse.py:122) the element count and
+ * sum (gt - pred)^2; per sample sum p*t, sum p, sum t, sum p^2, sum t^2.  fp64 accumulation, fixed summation order
+ * (bit-reproducible).  The weights' mean (w_mse.py:144) is sum_k cnt_k w_k / n.
+ * ------------------------------------------------------------------------- */
+#define SN_LOSS_MAX_BINS 16
+#define SN_LOSS_NSTAT(H) (2 * (H) + 5)            /* cnt[H], sq_err[H], sum_pt, sum_p, sum_t, sum_pp, sum_tt */
+#define SN_LOSS_PARTS(n_per) ((n_per) <= 8192 ? 1 : ((n_per) >= 8192 * 256 ? 256 : (int)(((n_per) + 8191) / 8192)))
+#define SN_LOSS_WS_DOUBLES(B, n_per, H) ((int64_t)(B) * SN_LOSS_PARTS(n_per) * SN_LOSS_NSTAT(H))
+#define SN_LOSS_NCOEF(B) (SN_LOSS_MAX_BINS + 3 * (B))
+typedef enum { SN_LOSS_WMSE = 1, SN_LOSS_FOCAL_TVERSKY = 2, SN_LOSS_DICE = 4 } sn_loss_term;
+
+/* Forward.  pred [B, n_per] (SN_F32 | SN_F64), gt [B, n_per] (SN_F32 | SN_F64 | SN_U8 | SN_OCC8),
+ * ranges [H] f32 (left bin edges, w_mse.py:100), bin_w [H] f32 = max(1 - alpha*dens_k, eps) per bin BEFORE the
+ * division by the mean (w_mse.py:128-142; ~10 numbers the host derives from the frequency table once).
+ * terms = OR of sn_loss_term.  Outputs: stats [B, SN_LOSS_NSTAT(H)] f64; loss [4] f64 = {sum of the requested terms,
+ * weighted MSE, focal Tversky, dice}; coef [SN_LOSS_NCOEF(B)] f64 for sn_loss_backward.
+ * parts_ws: scratch [SN_LOSS_WS_DOUBLES(B, n_per, H)] f64. */
+int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                    const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                    double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                    double dice_smooth, double* parts_ws, double* stats, double* loss, double* coef,
+                    sn_stream_t stream);
+
+/* Backward: grad_pred[b,i] = up * (coef[bin(gt)] (p - t) + A_b t + B_b + C_b p), in pred's dtype.
+ * upstream: device scalar f64 (dL/dloss), NULL = 1. */
+int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                     const float* ranges, int H, const double* coef, const double* upstream, void* grad_pred,
+                     sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

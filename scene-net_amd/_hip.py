@@ -42,7 +42,12 @@ SYMBOLS = {
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sn_loss_forward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
+                        + [_P, _P, _P, _P, _P]),
+    "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
 }
+SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE = 1, 2, 4
+SN_LOSS_MAX_BINS = 16
 SN_OCC_PARTS = 16
 SN_BBOX_PARTS = 32
 OCC_MAX_WORDS = 16 * 1024
@@ -301,3 +306,47 @@ def geneo_bank_bwd(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Seque
                                   ky, _ptr(dW, torch.float32, "dW"), _ptr(dparams), _stream())
     _check(rc, "sn_geneo_bank_bwd")
     return dparams
+
+
+# --------------------------------------------------------------------------- #
+def loss_parts(n_per: int) -> int:
+    """SN_LOSS_PARTS of include/scenenet_hip.h."""
+    return 1 if n_per <= 8192 else min(256, (n_per + 8191) // 8192)
+
+
+def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int,
+                 mse_weight: float = 1.0, tversky_alpha: float = 0.5, tversky_beta: float = 1.0,
+                 focal_gamma: float = 1.0, tversky_smooth: float = 1.0, dice_smooth: float = 1.0):
+    """sn_loss_forward on pred/gt [B, ...] (same shape).  Returns (loss [4] f64 = {total, wmse, focal tversky, dice},
+    stats [B, 2H+5] f64, coef f64 for loss_backward)."""
+    if pred.shape != gt.shape:
+        raise HipLibraryError(f"pred {tuple(pred.shape)} and gt {tuple(gt.shape)} must have the same shape")
+    B = int(pred.shape[0])
+    n_per = pred.numel() // max(B, 1)
+    H = int(ranges.numel())
+    dev = pred.device
+    ws = torch.empty((B * loss_parts(n_per) * (2 * H + 5),), dtype=torch.float64, device=dev)
+    stats = torch.empty((B, 2 * H + 5), dtype=torch.float64, device=dev)
+    loss = torch.empty((4,), dtype=torch.float64, device=dev)
+    coef = torch.empty((SN_LOSS_MAX_BINS + 3 * B,), dtype=torch.float64, device=dev)
+    rc = load().sn_loss_forward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
+                                n_per, _ptr(ranges, torch.float32, "ranges"), _ptr(bin_w, torch.float32, "bin_w"), H,
+                                int(terms), float(mse_weight), float(tversky_alpha), float(tversky_beta),
+                                float(focal_gamma), float(tversky_smooth), float(dice_smooth), _ptr(ws), _ptr(stats),
+                                _ptr(loss), _ptr(coef), _stream())
+    _check(rc, "sn_loss_forward")
+    return loss, stats, coef
+
+
+def loss_backward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, coef: torch.Tensor,
+                  upstream: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dL/dpred (pred's dtype and shape) from the coefficients of loss_forward (sn_loss_backward)."""
+    B = int(pred.shape[0])
+    n_per = pred.numel() // max(B, 1)
+    grad = torch.empty_like(pred)
+    rc = load().sn_loss_backward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
+                                 n_per, _ptr(ranges, torch.float32, "ranges"), int(ranges.numel()),
+                                 _ptr(coef, torch.float64, "coef"), _ptr(upstream, torch.float64, "upstream"),
+                                 _ptr(grad), _stream())
+    _check(rc, "sn_loss_backward")
+    return grad

@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's training criteria for SCENE-Net, over csrc/loss.hip.
+
+Same class names, constructor arguments, `forward` signatures and hyper-parameter meaning as
+core/criterions/{w_mse,tversky_loss,dice_loss,geneo_loss}.py, so `LitSceneNet` (lit_model_wrappers.py:160-200) takes
+them unchanged.  What differs is how the numbers are produced: every dense term (weighted MSE, focal Tversky, dice) of
+one criterion comes out of ONE streaming pass over (pred, gt) on the GPU (`sn_loss_forward`), and the gradient w.r.t.
+the prediction out of a second one (`sn_loss_backward`); sums are fp64 in a fixed order.  The penalties over the ~50
+scalar parameters (cvx_loss, positive_regularizer) are three torch ops on a stacked vector.
+
+There is no CPU path: pred / gt must be HIP tensors.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Optional, Tuple
+
+import torch
+
+from . import _hip
+
+HIST_PATH = os.path.join(os.getcwd(), "hist_estimation.pickle")  # w_mse.py:21
+ALPHA, BETA, GAMMA = 0.5, 1, 2  # tversky_loss.py:5-7
+
+
+def save_pickle(data, filename):
+    with open(filename, "wb") as handle:
+        pickle.dump(data, handle)
+
+
+def load_pickle(filename):
+    with open(filename, "rb") as handle:
+        return pickle.load(handle)
+
+
+class _DenseLossFn(torch.autograd.Function):
+    """loss [4] = {sum of terms, wmse, focal tversky, dice} as one differentiable op (gradient flows from any of the
+    four entries; they are linear in each other's coefficients only through entry 0, which is what criteria use)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, ranges, bin_w, terms, cfg):
+        pred_c, gt_c = pred.contiguous(), gt.contiguous()
+        loss, stats, coef = _hip.loss_forward(pred_c, gt_c, ranges, bin_w, terms, **cfg)
+        ctx.save_for_backward(pred_c, gt_c, ranges, coef)
+        ctx.mark_non_differentiable(stats)
+        return loss[0].to(pred.dtype), stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        pred, gt, ranges, coef = ctx.saved_tensors
+        up = g_loss.detach().to(torch.float64).reshape(1).contiguous()
+        return _hip.loss_backward(pred, gt, ranges, coef, up), None, None, None, None, None
+
+
+def _dense_loss(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int, **cfg):
+    pred, gt = torch.broadcast_tensors(pred, gt)  # w_mse.py:147
+    if pred.dim() == 0:
+        pred, gt = pred.reshape(1, 1), gt.reshape(1, 1)
+    elif pred.dim() == 1:
+        pred, gt = pred.reshape(1, -1), gt.reshape(1, -1)
+    loss, _ = _DenseLossFn.apply(pred, gt, ranges, bin_w, terms, cfg)
+    return loss
+
+
+_UNIT = {}
+
+
+def _unit_tables(device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A one-bin table for criteria that carry no weighting scheme (Tversky / dice alone)."""
+    key = str(device)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.zeros(1, dtype=torch.float32, device=device), torch.ones(1, dtype=torch.float32, device=device))
+    return _UNIT[key]
+
+
+class WeightedMSE(torch.nn.Module):
+    """w_mse.py:24-151.  Weighted MSE whose weights come from an inverse-frequency histogram of the targets."""
+
+    def __init__(self, targets=None, weighting_scheme_path=HIST_PATH, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
+                 **kwargs) -> None:
+        super().__init__()
+        self.weight_alpha = weight_alpha
+        self.weight_epsilon = weight_epsilon
+        self.mse_weight = mse_weight
+        self.relu = torch.nn.ReLU()
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")  # w_mse.py:57
+        if weighting_scheme_path is not None and os.path.exists(weighting_scheme_path):
+            self.pik_name = weighting_scheme_path
+            self.freqs, self.ranges = load_pickle(self.pik_name)
+        elif targets is not None:
+            self.freqs, self.ranges = self.hist_frequency_estimation(torch.flatten(targets), plot=False)
+            if kwargs.get("save_weighting_scheme", True):  # w_mse.py:65 writes ./hist_estimation.pickle
+                save_pickle((self.freqs.cpu(), self.ranges.cpu()), os.path.join(".", "hist_estimation.pickle"))
+        else:
+            # the reference builds this ValueError without raising it (w_mse.py:67) and dies on the next line
+            raise ValueError("No targets were provided to build the weighting scheme")
+        self.freqs = self.freqs.to(self.device)
+        self.ranges = self.ranges.to(self.device)
+        self._tables = {}
+
+    def hist_frequency_estimation(self, y: torch.Tensor, hist_len=10, plot=False):
+        """w_mse.py:72-112: counts per bin int(hist_len*y); ranges = left edges."""
+        hist_range = torch.linspace(0, 1, hist_len + 1, device=self.device)[:-1]
+        y = y.to(self.device)
+        hist_idxs = (hist_len * y).to(torch.int)
+        hist_count = torch.bincount(hist_idxs, minlength=hist_len)
+        if plot:
+            print("Histogram Bin /\t Count")
+            step = hist_range[1] - hist_range[0]
+            for i in range(len(hist_range)):
+                print(f"[{hist_range[i]:.3f}, {hist_range[i] + step:.3f}[ : {hist_count[i]}")
+        return hist_count, hist_range
+
+    # -- the ~10-entry tables everything else derives from ------------------------------------------------------
+    def _bin_values(self) -> torch.Tensor:
+        """Value each starting bin ends with after w_mse.py:124-126, whose in-place loop re-replaces a frequency
+        that equals a later bin index."""
+        freqs = [int(f) for f in self.freqs.tolist()]
+        out = []
+        for k in range(len(self.ranges)):
+            v = k
+            for idx, f in enumerate(freqs):
+                if v == idx:
+                    v = f
+            out.append(v)
+        return torch.tensor(out, dtype=torch.int64)
+
+    def _bin_weights(self) -> torch.Tensor:
+        """max(1 - alpha*dens, eps) per bin in fp32 (w_mse.py:128-142), before the division by the mean."""
+        vals = self._bin_values()
+        freqs = self.freqs.cpu()
+        fmin, fmax = torch.min(freqs), torch.max(freqs)
+        dens = (vals - fmin) / (fmax - fmin)
+        return torch.max(1 - self.weight_alpha * dens, torch.full_like(dens, self.weight_epsilon))
+
+    def _device_tables(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = (str(device), float(self.weight_alpha), float(self.weight_epsilon), id(self.freqs), self.freqs._version,
+               id(self.ranges))
+        if key not in self._tables:
+            self._tables.clear()
+            self._tables[key] = (self.ranges.to(device=device, dtype=torch.float32).contiguous(),
+                                 self._bin_weights().to(device=device, dtype=torch.float32).contiguous())
+        return self._tables[key]
+
+    def get_dens_target(self, y: torch.Tensor, calc_weights=False):
+        """w_mse.py:114-131 (table lookup instead of the in-place loop; same values)."""
+        if calc_weights:
+            self.freqs, self.ranges = self.hist_frequency_estimation(y)
+            self._tables.clear()
+        hist_idx = torch.abs(torch.unsqueeze(y, -1) - self.ranges.to(y.device)).argmin(dim=-1)
+        vals = self._bin_values().to(y.device)[hist_idx]
+        freq_min, freq_max = torch.min(self.freqs), torch.max(self.freqs)
+        return (vals - freq_min.to(y.device)) / (freq_max - freq_min).to(y.device)
+
+    def get_weight_target(self, y: torch.Tensor):
+        """w_mse.py:133-144."""
+        y = y.to(self.device)
+        y_dens = self.get_dens_target(y)
+        weights = torch.max(1 - self.weight_alpha * y_dens, torch.full_like(y_dens, self.weight_epsilon))
+        return weights / torch.mean(weights)
+
+    def _dense(self, y_pred, y_gt, terms, **cfg):
+        ranges, bin_w = self._device_tables(y_pred.device)
+        return _dense_loss(y_pred, y_gt, ranges, bin_w, terms, mse_weight=self.mse_weight, **cfg)
+
+    def forward(self, y_pred: torch.Tensor, y_gt: torch.Tensor):
+        """w_mse.py:146-151."""
+        return self._dense(y_pred, y_gt, _hip.SN_LOSS_WMSE)
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parser = parent_parser.add_argument_group("WeightedMSE")
+        parser.add_argument("--weight_alpha", type=float, default=1)
+        parser.add_argument("--weight_epsilon", type=float, default=0.01)
+        parser.add_argument("--mse_weight", type=float, default=1)
+        parser.add_argument("--hist_path", type=str, default=HIST_PATH)
+        return parent_parser
+
+
+class TverskyLoss(torch.nn.Module):
+    """tversky_loss.py:10-60."""
+
+    def __init__(self, tversky_alpha=ALPHA, tversky_beta=BETA, tversky_smooth=1, **kwargs):
+        super().__init__()
+        self.tversky_alpha = tversky_alpha
+        self.tversky_beta = tversky_beta
+        self.tversky_smooth = tversky_smooth
+
+    def _cfg(self, gamma=1.0):
+        return dict(tversky_alpha=self.tversky_alpha, tversky_beta=self.tversky_beta, focal_gamma=gamma,
+                    tversky_smooth=self.tversky_smooth)
+
+    def forward(self, inputs, targets):
+        ranges, bin_w = _unit_tables(inputs.device)
+        return _dense_loss(inputs, targets, ranges, bin_w, _hip.SN_LOSS_FOCAL_TVERSKY, **self._cfg(1.0))
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parser = parent_parser.add_argument_group("TverskyLoss")
+        parser.add_argument("--tversky_alpha", type=float, default=ALPHA)
+        parser.add_argument("--tversky_beta", type=float, default=BETA)
+        parser.add_argument("--tversky_smooth", type=float, default=1)
+        return parent_parser
+
+
+class FocalTverskyLoss(TverskyLoss):
+    """tversky_loss.py:63-103."""
+
+    def __init__(self, tversky_alpha=ALPHA, tversky_beta=BETA, focal_gamma=GAMMA, tversky_smooth=1, **kwargs):
+        super().__init__(tversky_alpha, tversky_beta, tversky_smooth)
+        self.focal_gamma = focal_gamma
+
+    def forward(self, inputs, targets):
+        ranges, bin_w = _unit_tables(inputs.device)
+        return _dense_loss(inputs, targets, ranges, bin_w, _hip.SN_LOSS_FOCAL_TVERSKY, **self._cfg(self.focal_gamma))
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parser = parent_parser.add_argument_group("FocalTverskyLoss")
+        parser.add_argument("--tversky_alpha", type=float, default=ALPHA)
+        parser.add_argument("--tversky_beta", type=float, default=BETA)
+        parser.add_argument("--focal_gamma", type=float, default=GAMMA)
+        parser.add_argument("--tversky_smooth", type=float, default=1)
+        return parent_parser
+
+
+class BinaryDiceLoss(torch.nn.Module):
+    """dice_loss.py:8-51 (p = 2; reduction 'mean' or 'sum')."""
+
+    def __init__(self, smooth=1, p=2, reduction="mean", **kwargs):
+        super().__init__()
+        if p != 2:
+            raise NotImplementedError("BinaryDiceLoss on the HIP path is built for p = 2 (the reference's default)")
+        if reduction not in ("mean", "sum"):
+            raise NotImplementedError("BinaryDiceLoss on the HIP path: reduction 'mean' or 'sum'")
+        self.smooth = smooth
+        self.power = p
+        self.reduction = reduction
+
+    def forward(self, predict, target):
+        assert predict.shape[0] == target.shape[0], "predict & target batch size don't match"
+        ranges, bin_w = _unit_tables(predict.device)
+        loss = _dense_loss(predict, target, ranges, bin_w, _hip.SN_LOSS_DICE, dice_smooth=self.smooth)
+        return loss if self.reduction == "mean" else loss * predict.shape[0]
+
+
+class GENEO_Loss(WeightedMSE):
+    """geneo_loss.py:24-90: weighted MSE + penalties on non-positive convex coefficients / GENEO parameters."""
+
+    def __init__(self, targets=None, weighting_scheme_path=HIST_PATH, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
+                 convex_weight=1, **kwargs) -> None:
+        super().__init__(targets, weighting_scheme_path, weight_alpha, weight_epsilon, mse_weight, **kwargs)
+        self.cvx_w = convex_weight
+
+    def cvx_loss(self, cvx_coeffs):
+        """geneo_loss.py:36-61: relu(-phi) over the trainable coefficients, plus relu(-(1 - sum of them)) for the
+        frozen last one."""
+        if len(cvx_coeffs) == 0:
+            return 0
+        last_phi = [n for n in cvx_coeffs if not cvx_coeffs[n].requires_grad][0]
+        free = torch.stack([phi for n, phi in cvx_coeffs.items() if n != last_phi])
+        return self.cvx_w * (torch.relu(-free).sum() + torch.relu(-(1 - free.sum())))
+
+    def positive_regularizer(self, params):
+        """geneo_loss.py:63-70."""
+        if len(params) == 0:
+            return 0
+        return self.cvx_w * torch.relu(-torch.stack(list(params.values()))).sum()
+
+    def _terms(self):
+        return _hip.SN_LOSS_WMSE, {}
+
+    def forward(self, y_pred, y_gt, cvx_coeffs, geneo_params):
+        terms, cfg = self._terms()
+        dense_criterion = self._dense(y_pred, y_gt, terms, **cfg)
+        return dense_criterion + self.cvx_loss(cvx_coeffs) + self.positive_regularizer(geneo_params)
+
+    def __str__(self):
+        return f"GENEO Loss with mse_weight={self.mse_weight} and alpha={self.weight_alpha} and epsilon={self.weight_epsilon}"
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parent_parser = WeightedMSE.add_model_specific_args(parent_parser)
+        parser = parent_parser.add_argument_group("GENEO_Loss")
+        parser.add_argument("--cvx_w", type=float, default=1.0)
+        return parent_parser
+
+
+class GENEO_Dice_Loss(GENEO_Loss):
+    """geneo_loss.py:131-143: weighted MSE + BinaryDiceLoss + penalties -- one pass over (pred, gt)."""
+
+    def __init__(self, targets=None, weighting_scheme_path=None, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
+                 convex_weight=1, **kwargs) -> None:
+        super().__init__(targets, weighting_scheme_path, weight_alpha, weight_epsilon, mse_weight, convex_weight,
+                         **kwargs)
+        self.dice = BinaryDiceLoss()
+
+    def _terms(self):
+        return _hip.SN_LOSS_WMSE | _hip.SN_LOSS_DICE, dict(dice_smooth=self.dice.smooth)
+
+
+class GENEO_Tversky_Loss(GENEO_Loss):
+    """geneo_loss.py:145-161: weighted MSE + FocalTverskyLoss + penalties -- one pass over (pred, gt)."""
+
+    def __init__(self, targets=None, weighting_scheme_path=None, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
+                 convex_weight=1, tversky_alpha=0.5, tversky_beta=1, focal_gamma=1, tversky_smooth=1, **kwargs) -> None:
+        super().__init__(targets, weighting_scheme_path, weight_alpha, weight_epsilon, mse_weight, convex_weight,
+                         **kwargs)
+        self.tversky = FocalTverskyLoss(tversky_alpha, tversky_beta, focal_gamma, tversky_smooth)
+
+    def _terms(self):
+        return _hip.SN_LOSS_WMSE | _hip.SN_LOSS_FOCAL_TVERSKY, self.tversky._cfg(self.tversky.focal_gamma)
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parent_parser = GENEO_Loss.add_model_specific_args(parent_parser)
+        return FocalTverskyLoss.add_model_specific_args(parent_parser)

@@ -10,6 +10,13 @@
 // symmetric projection, so dL/dtheta = < P(dW), df/dtheta >.
 #include "common.h"
 
+namespace sn {  // corr.hip
+int corr_mfma_supported(int kz, int kx, int ky);
+int corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky);
+int corr_mfma_launch(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X, int Y,
+                     int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
+}  // namespace sn
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -241,6 +248,9 @@ extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const
     if (!x || !gout || !partial_ws || !C) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr: null pointer");
     if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr: non-positive extent");
+    // matrix-core kernel (corr.hip) for every kernel extent <= 16; the thread-per-tap kernel below serves the rest
+    if (sn::corr_mfma_supported(kz, kx, ky) && sn::corr_mfma_rows(B, Z, X, Y, kz, kx, ky) > 0)
+        return sn::corr_mfma_launch(x, x_dtype, gout, out, B, Z, X, Y, kz, kx, ky, partial_ws, C, sn::as_stream(stream));
     const int nzt = (Z + TZ - 1) / TZ, nxt = (X + TX - 1) / TX, nyt = (Y + TY - 1) / TY;
     const size_t lds = ((size_t)(TZ + kz - 1) * (TX + kx - 1) * (TY + ky - 1) + (size_t)TZ * TX * TY) * sizeof(float);
     if (lds > 150 * 1024) return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr: kernel %dx%dx%d too large", kz, kx, ky);
@@ -269,7 +279,8 @@ extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const
 
 extern "C" int sn_conv_corr_blocks(int B, int Z, int X, int Y) {
     if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0) return 0;
-    return B * ((Z + TZ - 1) / TZ) * ((X + TX - 1) / TX) * ((Y + TY - 1) / TY);
+    const long tiles = (long)B * ((Z + TZ - 1) / TZ) * ((X + TX - 1) / TX) * ((Y + TY - 1) / TY);
+    return (int)(tiles > 768 ? tiles : 768);  // the matrix-core kernel writes at most 768 partial rows
 }
 
 extern "C" int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,

@@ -1,0 +1,367 @@
+// K5 -- training criterion on the prediction grid: one streaming pass over (pred, gt) gives every sum
+// the reference's WeightedMSE / FocalTversky / BinaryDice need; a one-block kernel turns them into the loss and the
+// coefficients of its gradient; a second streaming pass writes dL/dpred.
+//
+// Reference (what is restated, not how): core/criterions/w_mse.py:114-151, tversky_loss.py:81-95,
+// dice_loss.py:33-51, geneo_loss.py:72-81, :131-161.
+//
+// Bound: HBM.  Algorithmic bytes per element: forward sizeof(pred) + sizeof(gt); backward the same + sizeof(pred)
+// written.  All accumulation is fp64 in a fixed order (per-thread strided, wave shuffle tree, waves in order, parts
+// in order), so a loss value is bit-reproducible.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBins = SN_LOSS_MAX_BINS;
+
+template <typename T>
+struct Vec4 {
+    T v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ Vec4<T> load4(const T* p) {
+    Vec4<T> r;
+    if constexpr (sizeof(T) == 4) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        __builtin_memcpy(&r, &u, 16);
+    } else if constexpr (sizeof(T) == 8) {
+        const uint4 u0 = reinterpret_cast<const uint4*>(p)[0], u1 = reinterpret_cast<const uint4*>(p)[1];
+        __builtin_memcpy(&r.v[0], &u0, 16);
+        __builtin_memcpy(&r.v[2], &u1, 16);
+    } else {
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+        __builtin_memcpy(&r, &u, 4);
+    }
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const Vec4<T>& r) {
+    if constexpr (sizeof(T) == 4) {
+        uint4 u;
+        __builtin_memcpy(&u, &r, 16);
+        *reinterpret_cast<uint4*>(p) = u;
+    } else {
+        uint4 u0, u1;
+        __builtin_memcpy(&u0, &r.v[0], 16);
+        __builtin_memcpy(&u1, &r.v[2], 16);
+        reinterpret_cast<uint4*>(p)[0] = u0;
+        reinterpret_cast<uint4*>(p)[1] = u1;
+    }
+}
+
+// w_mse.py:122 -- argmin_k |y - ranges[k]|, first minimum; arithmetic in gt's dtype promoted with the fp32 ranges
+// (f64 gt: fp64; f32 gt: fp32; byte gt, our extension: fp32).
+template <typename GT>
+struct BinOf {
+    using C = typename std::conditional<std::is_same<GT, double>::value, double, float>::type;
+    C r[kMaxBins];
+    int H;
+    __device__ void init(const float* ranges, int h) {
+        H = h;
+#pragma unroll
+        for (int k = 0; k < kMaxBins; ++k) r[k] = (C)ranges[k < h ? k : h - 1];
+    }
+    __device__ __forceinline__ int operator()(GT y) const {
+        const C yy = (C)y;
+        C best = fabs(yy - r[0]);
+        int idx = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxBins; ++k) {
+            const C d = fabs(yy - r[k]);
+            const bool lt = (k < H) && (d < best);
+            best = lt ? d : best;
+            idx = lt ? k : idx;
+        }
+        return idx;
+    }
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- pass 1: partial statistics
+// grid = (parts, B); block `part` owns elements [part*span, (part+1)*span) of sample b (span a multiple of 4).
+template <typename PT, typename GT>
+__global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restrict__ pred, const GT* __restrict__ gt,
+                                                              long n_per, long span, const float* __restrict__ ranges,
+                                                              int H, double* __restrict__ parts) {
+    __shared__ double red[kThreads / 64][2 * kMaxBins + 5];
+    const int part = blockIdx.x, b = blockIdx.y, nparts = gridDim.x;
+    const long lo = (long)part * span, hi = (lo + span < n_per) ? lo + span : n_per;
+    const PT* p = pred + (size_t)b * n_per;
+    const GT* t = gt + (size_t)b * n_per;
+    BinOf<GT> bin;
+    bin.init(ranges, H);
+
+    double cnt[kMaxBins], sq[kMaxBins];
+#pragma unroll
+    for (int k = 0; k < kMaxBins; ++k) cnt[k] = 0.0, sq[k] = 0.0;
+    double s_pt = 0, s_p = 0, s_t = 0, s_pp = 0, s_tt = 0;
+
+    auto take = [&](PT pv, GT tv) {
+        const double pd = (double)pv, td = (double)tv;
+        const double e = td - pd;
+        const int k = bin(tv);
+#pragma unroll
+        for (int j = 0; j < kMaxBins; ++j) {
+            const bool m = (j == k);
+            cnt[j] += m ? 1.0 : 0.0;
+            sq[j] += m ? e * e : 0.0;
+        }
+        s_pt += pd * td;
+        s_p += pd;
+        s_t += td;
+        s_pp += pd * pd;
+        s_tt += td * td;
+    };
+
+    // vector body: the sample base is 4-element aligned when n_per % 4 == 0 (host checks pointer alignment)
+    const bool vec = (n_per % 4 == 0);
+    if (vec) {
+        for (long i = lo + 4 * (long)threadIdx.x; i + 3 < hi; i += 4 * kThreads) {
+            const Vec4<PT> pv = load4(p + i);
+            const Vec4<GT> tv = load4(t + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) take(pv.v[j], tv.v[j]);
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) take(p[i], t[i]);
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nstat = 2 * H + 5;
+    for (int j = 0; j < kMaxBins; ++j) {
+        if (j < H) {
+            const double a = wave_sum(cnt[j]), c = wave_sum(sq[j]);
+            if (lane == 0) red[wave][j] = a, red[wave][H + j] = c;
+        }
+    }
+    {
+        const double a = wave_sum(s_pt), c = wave_sum(s_p), d = wave_sum(s_t), e = wave_sum(s_pp), f = wave_sum(s_tt);
+        if (lane == 0) {
+            red[wave][2 * H + 0] = a; red[wave][2 * H + 1] = c; red[wave][2 * H + 2] = d;
+            red[wave][2 * H + 3] = e; red[wave][2 * H + 4] = f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nstat) {
+        double s = 0;
+        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
+        parts[((size_t)b * nparts + part) * nstat + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------- one block: parts -> stats -> loss + coefficients
+struct LossCfg {
+    int terms;
+    double mse_weight, tv_alpha, tv_beta, gamma, tv_smooth, dice_smooth;
+};
+
+__global__ __launch_bounds__(kThreads) void loss_combine_kernel(const double* __restrict__ parts, int B, int nparts,
+                                                                long n_per, int H, const float* __restrict__ bin_w,
+                                                                LossCfg cfg, double* __restrict__ stats,
+                                                                double* __restrict__ loss, double* __restrict__ coef) {
+    __shared__ double tot[2 * kMaxBins + 5];
+    __shared__ double dice_part[kThreads];
+    const int nstat = 2 * H + 5;
+    for (int i = threadIdx.x; i < B * nstat; i += kThreads) {
+        const int b = i / nstat, j = i % nstat;
+        double s = 0;
+        for (int q = 0; q < nparts; ++q) s += parts[((size_t)b * nparts + q) * nstat + j];
+        stats[i] = s;
+    }
+    __syncthreads();  // stats[] written by this block is visible to it after the barrier
+    if (threadIdx.x < nstat) {
+        double s = 0;
+        for (int b = 0; b < B; ++b) s += stats[(size_t)b * nstat + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    // dice, per sample (dice_loss.py:38-41), mean over the batch; gradient coefficients per sample
+    double dsum = 0;
+    for (int b = threadIdx.x; b < B; b += kThreads) {
+        double A = 0, C = 0;
+        if (cfg.terms & SN_LOSS_DICE) {
+            const double* s = stats + (size_t)b * nstat + 2 * H;
+            const double num = s[0] + cfg.dice_smooth, den = s[3] + s[4] + cfg.dice_smooth;
+            dsum += 1.0 - num / den;
+            A = -1.0 / den / B;               // d(1 - num/den)/dp_i = -(t_i den - num 2 p_i)/den^2
+            C = 2.0 * num / (den * den) / B;
+        }
+        coef[kMaxBins + 3 * b + 0] = A;
+        coef[kMaxBins + 3 * b + 1] = 0.0;
+        coef[kMaxBins + 3 * b + 2] = C;
+    }
+    dice_part[threadIdx.x] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)B * (double)n_per;
+        double wmse = 0, focal = 0, dice = 0;
+        double mean_w = 0;
+        for (int k = 0; k < H; ++k) mean_w += tot[k] * (double)bin_w[k];
+        mean_w /= n;
+        for (int k = 0; k < kMaxBins; ++k) {
+            double c = 0;
+            if (k < H && (cfg.terms & SN_LOSS_WMSE)) {
+                const double wk = (double)bin_w[k] / mean_w;       // w_mse.py:144
+                wmse += wk * tot[H + k];
+                c = 2.0 * cfg.mse_weight * wk / n;                 // d/dp of mean(mse_weight w (t - p)^2)
+            }
+            coef[k] = c;
+        }
+        wmse = (cfg.terms & SN_LOSS_WMSE) ? cfg.mse_weight * wmse / n : 0.0;
+        double tA = 0, tB = 0;
+        if (cfg.terms & SN_LOSS_FOCAL_TVERSKY) {                   // tversky_loss.py:86-93
+            const double TP = tot[2 * H], FP = tot[2 * H + 1] - TP, FN = tot[2 * H + 2] - TP;
+            const double a = cfg.tv_alpha, be = cfg.tv_beta, sm = cfg.tv_smooth, g = cfg.gamma;
+            const double N = TP + sm, D = TP + a * FP + be * FN + sm;
+            const double T = N / D, u = 1.0 - T;
+            focal = pow(u, g);
+            const double dF = -g * pow(u, g - 1.0);                // dFocal/dT
+            tA = dF * (D - N * (1.0 - a - be)) / (D * D);          // dT/dp_i = (t_i D - N (t_i (1-a-b) + a)) / D^2
+            tB = dF * (-N * a) / (D * D);
+        }
+        if (cfg.terms & SN_LOSS_DICE) {
+            for (int i = 0; i < kThreads; ++i) dice += dice_part[i];
+            dice /= B;
+        }
+        for (int b = 0; b < B; ++b) {
+            coef[kMaxBins + 3 * b + 0] += tA;
+            coef[kMaxBins + 3 * b + 1] += tB;
+        }
+        loss[0] = wmse + focal + dice;
+        loss[1] = wmse;
+        loss[2] = focal;
+        loss[3] = dice;
+    }
+}
+
+// ---------------------------------------------------------------- pass 2: dL/dpred
+template <typename PT, typename GT>
+__global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restrict__ pred, const GT* __restrict__ gt,
+                                                             long n_per, long span, const float* __restrict__ ranges,
+                                                             int H, const double* __restrict__ coef,
+                                                             const double* __restrict__ upstream,
+                                                             PT* __restrict__ grad) {
+    using C = PT;  // gradient arithmetic in pred's dtype
+    const int part = blockIdx.x, b = blockIdx.y;
+    const long lo = (long)part * span, hi = (lo + span < n_per) ? lo + span : n_per;
+    const PT* p = pred + (size_t)b * n_per;
+    const GT* t = gt + (size_t)b * n_per;
+    PT* g = grad + (size_t)b * n_per;
+    BinOf<GT> bin;
+    bin.init(ranges, H);
+    const double up = upstream ? *upstream : 1.0;
+    C ck[kMaxBins];
+#pragma unroll
+    for (int k = 0; k < kMaxBins; ++k) ck[k] = (C)(coef[k] * up);
+    const C A = (C)(coef[kMaxBins + 3 * b] * up), Bc = (C)(coef[kMaxBins + 3 * b + 1] * up),
+            Cc = (C)(coef[kMaxBins + 3 * b + 2] * up);
+    auto one = [&](PT pv, GT tv) -> PT {
+        const int k = bin(tv);
+        C c = ck[0];
+#pragma unroll
+        for (int j = 1; j < kMaxBins; ++j) c = (j == k) ? ck[j] : c;
+        const C pc = (C)pv, tc = (C)tv;
+        return (PT)(c * (pc - tc) + A * tc + Bc + Cc * pc);
+    };
+    if (n_per % 4 == 0) {
+        for (long i = lo + 4 * (long)threadIdx.x; i + 3 < hi; i += 4 * kThreads) {
+            const Vec4<PT> pv = load4(p + i);
+            const Vec4<GT> tv = load4(t + i);
+            Vec4<PT> r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.v[j] = one(pv.v[j], tv.v[j]);
+            store4(g + i, r);
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) g[i] = one(p[i], t[i]);
+    }
+}
+
+int check_common(const char* fn, const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                 const float* ranges, int H) {
+    if (!pred || !gt || !ranges) return sn::fail(SN_ERR_INVALID_ARG, "%s: null pointer", fn);
+    if (B <= 0 || n_per <= 0) return sn::fail(SN_ERR_INVALID_ARG, "%s: B and n_per must be positive", fn);
+    if (H < 1 || H > kMaxBins) return sn::fail(SN_ERR_UNSUPPORTED, "%s: 1 <= H <= %d bins", fn, kMaxBins);
+    if (pred_dtype != SN_F32 && pred_dtype != SN_F64)
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: pred must be SN_F32 or SN_F64", fn);
+    if (gt_dtype != SN_F32 && gt_dtype != SN_F64 && gt_dtype != SN_U8 && gt_dtype != SN_OCC8)
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: bad gt dtype %d", fn, gt_dtype);
+    const size_t pa = 16, ga = (gt_dtype == SN_F64 || gt_dtype == SN_F32) ? 16 : 4;
+    if (n_per % 4 == 0 && (((uintptr_t)pred % pa) || ((uintptr_t)gt % ga)))
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: pred / gt must be 16-byte (byte gt: 4-byte) aligned", fn);
+    return SN_OK;
+}
+
+// span per part: a multiple of 4 so that the vector loop of every part starts aligned
+long span_of(int64_t n_per, int nparts) {
+    long s = (long)((n_per + nparts - 1) / nparts);
+    return (s + 3) / 4 * 4;
+}
+
+}  // namespace
+
+#define SN_LOSS_DISPATCH(KERNEL, ...)                                                                             \
+    do {                                                                                                          \
+        if (pred_dtype == SN_F32) {                                                                               \
+            if (gt_dtype == SN_F32) KERNEL(float, float, __VA_ARGS__);                                            \
+            else if (gt_dtype == SN_F64) KERNEL(float, double, __VA_ARGS__);                                      \
+            else KERNEL(float, uint8_t, __VA_ARGS__);                                                             \
+        } else {                                                                                                  \
+            if (gt_dtype == SN_F32) KERNEL(double, float, __VA_ARGS__);                                           \
+            else if (gt_dtype == SN_F64) KERNEL(double, double, __VA_ARGS__);                                     \
+            else KERNEL(double, uint8_t, __VA_ARGS__);                                                            \
+        }                                                                                                         \
+    } while (0)
+
+extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                               const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                               double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                               double dice_smooth, double* parts_ws, double* stats, double* loss, double* coef,
+                               sn_stream_t stream) {
+    if (int rc = check_common("sn_loss_forward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
+    if (!bin_w || !parts_ws || !stats || !loss || !coef)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_forward: null pointer");
+    if (terms <= 0 || (terms & ~(SN_LOSS_WMSE | SN_LOSS_FOCAL_TVERSKY | SN_LOSS_DICE)))
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_forward: bad terms mask %d", terms);
+    if (B > 65535) return sn::fail(SN_ERR_UNSUPPORTED, "sn_loss_forward: B <= 65535");
+    hipStream_t s = sn::as_stream(stream);
+    const int nparts = SN_LOSS_PARTS(n_per);
+    const long span = span_of(n_per, nparts);
+#define SN_STATS(PT, GT, ...)                                                                                     \
+    hipLaunchKernelGGL((loss_stats_kernel<PT, GT>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,       \
+                       (const GT*)gt, (long)n_per, span, ranges, H, parts_ws)
+    SN_LOSS_DISPATCH(SN_STATS, 0);
+#undef SN_STATS
+    if (int rc = sn::check_launch("sn_loss_forward(stats)")) return rc;
+    LossCfg cfg{terms, mse_weight, tversky_alpha, tversky_beta, focal_gamma, tversky_smooth, dice_smooth};
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kThreads), 0, s, parts_ws, B, nparts, (long)n_per, H, bin_w,
+                       cfg, stats, loss, coef);
+    return sn::check_launch("sn_loss_forward(combine)");
+}
+
+extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                const float* ranges, int H, const double* coef, const double* upstream,
+                                void* grad_pred, sn_stream_t stream) {
+    if (int rc = check_common("sn_loss_backward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
+    if (!coef || !grad_pred) return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: null pointer");
+    if (n_per % 4 == 0 && ((uintptr_t)grad_pred % 16))
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: grad_pred must be 16-byte aligned");
+    if (B > 65535) return sn::fail(SN_ERR_UNSUPPORTED, "sn_loss_backward: B <= 65535");
+    hipStream_t s = sn::as_stream(stream);
+    const int nparts = SN_LOSS_PARTS(n_per);
+    const long span = span_of(n_per, nparts);
+#define SN_GRAD(PT, GT, ...)                                                                                      \
+    hipLaunchKernelGGL((loss_grad_kernel<PT, GT>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,        \
+                       (const GT*)gt, (long)n_per, span, ranges, H, coef, upstream, (PT*)grad_pred)
+    SN_LOSS_DISPATCH(SN_GRAD, 0);
+#undef SN_GRAD
+    return sn::check_launch("sn_loss_backward");
+}

@@ -271,7 +271,80 @@ def dump_real_tile_subset():
     print("ts40k_sample575_subset.npy:", sub.shape)
 
 
+def dump_loss():
+    """Losses and gradients of the reference's own criterion classes (core/criterions/geneo_loss.py) on small
+    (pred, gt) pairs: GENEO_Loss, GENEO_Tversky_Loss, GENEO_Dice_Loss, plus WeightedMSE.get_weight_target and
+    hist_frequency_estimation.  The classes write ./hist_estimation.pickle, so they are built in a scratch cwd."""
+    import tempfile
+    from core.criterions.geneo_loss import GENEO_Dice_Loss, GENEO_Loss, GENEO_Tversky_Loss
+
+    cases = {
+        # name: (shape, dtype, gt kind, explicit freqs or None (estimate from gt), hyper-parameters)
+        "ratio_f32_estimated": ((2, 1, 8, 10, 12), torch.float32, "ratio", None, dict()),
+        "binary_f64_estimated": ((3, 1, 6, 8, 8), torch.float64, "binary", None,
+                                 dict(weight_alpha=2.0, weight_epsilon=0.01, mse_weight=3.0, convex_weight=2.0)),
+        "ratio_f64_large_freqs": ((2, 1, 8, 8, 8), torch.float64, "ratio",
+                                  [5_000_000, 1200, 800, 700, 650, 400, 300, 310, 150, 9000],
+                                  dict(tversky_alpha=0.3, tversky_beta=0.7, focal_gamma=2.0, tversky_smooth=0.5)),
+        "binary_f32_chain_freqs": ((1, 1, 8, 8, 16), torch.float32, "binary", [40, 3, 5, 7, 9, 2, 4, 6, 8, 11],
+                                   dict(weight_alpha=0.5, weight_epsilon=0.2, focal_gamma=1.5)),
+    }
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for ci, (name, (shape, dt, kind, freqs, hp)) in enumerate(cases.items()):
+                g = torch.Generator().manual_seed(100 + ci)
+                u = torch.rand(shape, generator=g, dtype=torch.float64)
+                if kind == "binary":
+                    gt = (u < 0.08).to(dt)
+                else:  # reg_on_voxel-like: mostly 0, some 1, some ratios in (0,1)
+                    r = torch.rand(shape, generator=g, dtype=torch.float64)
+                    gt = torch.where(u < 0.85, torch.zeros_like(r), torch.where(u < 0.92, torch.ones_like(r), r)).to(dt)
+                pred0 = torch.rand(shape, generator=g, dtype=torch.float64).to(dt)
+                names = ["lambda_cone_0", "lambda_cy_0", "lambda_cy_1", "lambda_neg_0"]
+                lam = [0.41, -0.07, 0.9, -0.24]  # last (frozen) = 1 - sum(others) = -0.24; one negative trainable
+                gpar = {"a_radius": 1.5, "b_sigma": -0.3, "c_neg_factor": 0.2, "d_cone_inc": -0.05}
+                for cls_name, cls in [("geneo", GENEO_Loss), ("tversky", GENEO_Tversky_Loss), ("dice", GENEO_Dice_Loss)]:
+                    crit = cls(targets=gt, weighting_scheme_path=None, **hp)
+                    est_freqs, est_ranges = crit.freqs.clone(), crit.ranges.clone()
+                    if freqs is not None:
+                        crit.freqs = torch.tensor(freqs, dtype=torch.int64)
+                    pred = pred0.clone().requires_grad_(True)
+                    cvx = torch.nn.ParameterDict({n: torch.nn.Parameter(torch.tensor(v), requires_grad=(n != names[-1]))
+                                                  for n, v in zip(names, lam)})
+                    gp = torch.nn.ParameterDict({n: torch.nn.Parameter(torch.tensor(v)) for n, v in gpar.items()})
+                    loss = cls.forward(crit, pred, gt, cvx, gp)
+                    loss.backward()
+                    out[f"{name}|{cls_name}|loss"] = loss.detach().numpy()
+                    out[f"{name}|{cls_name}|grad_pred"] = pred.grad.numpy()
+                    out[f"{name}|{cls_name}|grad_cvx"] = np.array(
+                        [0.0 if cvx[n].grad is None else float(cvx[n].grad) for n in names])
+                    out[f"{name}|{cls_name}|grad_params"] = np.array([float(gp[n].grad) for n in gpar])
+                out[f"{name}|pred"] = pred0.numpy()
+                out[f"{name}|gt"] = gt.numpy()
+                out[f"{name}|freqs"] = crit.freqs.numpy()
+                out[f"{name}|ranges"] = crit.ranges.numpy()
+                out[f"{name}|est_freqs"] = est_freqs.numpy()
+                out[f"{name}|weights"] = crit.get_weight_target(gt).numpy()
+                out[f"{name}|hp"] = np.array(repr(hp))
+                out[f"{name}|cvx_names"] = np.array(names)
+                out[f"{name}|cvx_values"] = np.array(lam, dtype=np.float32)
+                out[f"{name}|param_names"] = np.array(list(gpar))
+                out[f"{name}|param_values"] = np.array(list(gpar.values()), dtype=np.float32)
+        finally:
+            os.chdir(cwd)
+    out["cases"] = np.array(list(cases))
+    np.savez_compressed(os.path.join(OUT, "geneo_loss.npz"), **out)
+    print("geneo_loss.npz:", list(cases))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["loss"]:
+        dump_loss()
+        sys.exit(0)
+    dump_loss()
     dump_real_tile_subset()
     dump_voxel_normalize()
     dump_kernels()
