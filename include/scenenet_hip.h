@@ -87,6 +87,13 @@ int sn_get_option(const char* name);
 int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
                   float* bank, int32_t* status, sn_stream_t stream);
 
+/* The effective convex coefficients of SceneNet.forward (core/models/SCENE_Net.py:329-335):
+ * out[g] = lambdas[g] except out[last] = (1 - sum_i lambdas[order[i]]) + lambdas[last], the sum taken sequentially in
+ * fp32 in the order given (nn.ParameterDict order: names sorted) -- bit for bit what the reference's python `sum`
+ * yields.  lambdas [G] f32 is in/out: lambdas[last] is overwritten with out[last], the side effect of
+ * SCENE_Net.py:333 (the frozen parameter is refreshed by every forward).  order [G] i32, out [G] f32. */
+int sn_effective_lambdas(float* lambdas, const int32_t* order, int G, int last, float* out, sn_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * K3  GENEO bank convolution + convex-combination head
  * replaces: SceneNet.forward (core/models/SCENE_Net.py:322-339):

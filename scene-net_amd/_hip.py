@@ -30,6 +30,7 @@ SYMBOLS = {
     "sn_set_option": (c_int, [c_char_p, _I]),
     "sn_get_option": (c_int, [c_char_p]),
     "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sn_effective_lambdas": (c_int, [_P, _P, _I, _I, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
     "sn_voxel_desc": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
@@ -306,6 +307,16 @@ def geneo_bank_bwd(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Seque
                                   ky, _ptr(dW, torch.float32, "dW"), _ptr(dparams), _stream())
     _check(rc, "sn_geneo_bank_bwd")
     return dparams
+
+
+def effective_lambdas(lambdas: torch.Tensor, order: torch.Tensor, last: int) -> torch.Tensor:
+    """sn_effective_lambdas: [G] f32 effective coefficients; `lambdas[last]` is refreshed in place."""
+    G = int(lambdas.numel())
+    out = torch.empty((G,), dtype=torch.float32, device=lambdas.device)
+    rc = load().sn_effective_lambdas(_ptr(lambdas, torch.float32, "lambdas"), _ptr(order, torch.int32, "order"), G,
+                                     int(last), _ptr(out), _stream())
+    _check(rc, "sn_effective_lambdas")
+    return out
 
 
 # --------------------------------------------------------------------------- #

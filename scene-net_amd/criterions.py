@@ -62,6 +62,14 @@ def _dense_loss(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_
     return loss
 
 
+def _live_pack(container):
+    """(P, live) when `container` came from a scene_net_amd model whose latest differentiable forward gathered its
+    parameters into one vector P that is still current (scene_net._LivePack), else (None, None)."""
+    live = getattr(container, "_sn_live", None)
+    P = live.current() if live is not None else None
+    return (P, live) if P is not None else (None, None)
+
+
 _UNIT = {}
 
 
@@ -257,15 +265,21 @@ class GENEO_Loss(WeightedMSE):
         frozen last one."""
         if len(cvx_coeffs) == 0:
             return 0
-        last_phi = [n for n in cvx_coeffs if not cvx_coeffs[n].requires_grad][0]
-        free = torch.stack([phi for n, phi in cvx_coeffs.items() if n != last_phi])
+        P, live = _live_pack(cvx_coeffs)
+        if P is not None:   # the model's gathered parameter vector: one autograd node for all scalars
+            free = P.index_select(0, live.free_idx)
+        else:
+            last_phi = [n for n in cvx_coeffs if not cvx_coeffs[n].requires_grad][0]
+            free = torch.stack([phi for n, phi in cvx_coeffs.items() if n != last_phi])
         return self.cvx_w * (torch.relu(-free).sum() + torch.relu(-(1 - free.sum())))
 
     def positive_regularizer(self, params):
         """geneo_loss.py:63-70."""
         if len(params) == 0:
             return 0
-        return self.cvx_w * torch.relu(-torch.stack(list(params.values()))).sum()
+        P, live = _live_pack(params)
+        vals = P.index_select(0, live.param_idx) if P is not None else torch.stack(list(params.values()))
+        return self.cvx_w * torch.relu(-vals).sum()
 
     def _terms(self):
         return _hip.SN_LOSS_WMSE, {}

@@ -125,7 +125,28 @@ __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __res
     }
 }
 
+// SCENE_Net.py:329-335: the frozen coefficient is 1 - sum(all, in ParameterDict order) + itself, a sequential fp32
+// sum; one thread reproduces it bit for bit.  Also stores it back (the reference re-creates that parameter).
+__global__ void effective_lambdas_kernel(float* __restrict__ lambdas, const int32_t* __restrict__ order, int G,
+                                         int last, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int i = 0; i < G; ++i) total = __fadd_rn(total, lambdas[order[i]]);
+    const float eff = __fadd_rn(__fsub_rn(1.0f, total), lambdas[last]);
+    for (int g = 0; g < G; ++g) out[g] = (g == last) ? eff : lambdas[g];
+    lambdas[last] = eff;
+}
+
 }  // namespace
+
+extern "C" int sn_effective_lambdas(float* lambdas, const int32_t* order, int G, int last, float* out,
+                                    sn_stream_t stream) {
+    if (!lambdas || !order || !out) return sn::fail(SN_ERR_INVALID_ARG, "sn_effective_lambdas: null pointer");
+    if (G <= 0 || last < 0 || last >= G) return sn::fail(SN_ERR_INVALID_ARG, "sn_effective_lambdas: bad G / last");
+    hipLaunchKernelGGL(effective_lambdas_kernel, dim3(1), dim3(64), 0, sn::as_stream(stream), lambdas, order, G, last,
+                       out);
+    return sn::check_launch("sn_effective_lambdas");
+}
 
 extern "C" int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
                              int32_t* status, sn_stream_t stream) {

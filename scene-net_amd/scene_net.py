@@ -16,6 +16,50 @@ from . import _hip
 from .geneos import CLASS_OF_KEY, CLASS_OF_KEY_V1, GENEO_kernel_torch, pack_params
 
 
+_SLOT_OF = {"radius": _hip.SN_P_RADIUS, "sigma": _hip.SN_P_SIGMA, "apex": _hip.SN_P_APEX,
+            "cone_radius": _hip.SN_P_CONE_RADIUS, "cone_inc": _hip.SN_P_CONE_INC, "neg_factor": _hip.SN_P_NEG_FACTOR}
+
+
+class _LivePack:
+    """The packed-parameter tensor P of the latest differentiable forward.  The criteria (criterions.py) take their
+    penalties from P, so every scalar receives ONE gradient from ONE autograd node instead of being stacked again and
+    accumulated ~50 times.  Never copied or pickled with the module."""
+
+    def __init__(self):
+        self.packed = None        # P [G*SN_NPARAM + G] f32, non-leaf
+        self.versions = None      # parameter versions P was gathered at
+        self.leaves = ()          # the nn.Parameters, in slot order
+        self.param_idx = None     # device int64: slots that hold a GENEO parameter
+        self.free_idx = None      # device int64: slots of the trainable convex coefficients
+
+    def current(self):
+        """P if no parameter changed since it was gathered, else None."""
+        if self.packed is None or self.versions != tuple(p._version for p in self.leaves):
+            return None
+        return self.packed
+
+    def __deepcopy__(self, memo):
+        return _LivePack()
+
+    def __reduce__(self):
+        return (_LivePack, ())
+
+
+class _GatherParamsFn(torch.autograd.Function):
+    """leaves (0-dim nn.Parameters aliasing `flat`) -> P = copy of flat.  Backward hands every leaf its slot of dP
+    as a view: no per-parameter kernels in either direction."""
+
+    @staticmethod
+    def forward(ctx, flat, slots, *leaves):
+        ctx.slots = slots
+        return flat.clone()
+
+    @staticmethod
+    def backward(ctx, gP):
+        grads = tuple(gP[i] if need else None for i, need in zip(ctx.slots, ctx.needs_input_grad[2:]))
+        return (None, None) + grads
+
+
 class GENEO_Layer(nn.Module):
     """SCENE_Net.py:56-113."""
 
@@ -91,11 +135,15 @@ class SceneNet(nn.Module):
         self.lambdas_dict = nn.ParameterDict(d)
         self._pack_cache = None
         self._lambda_cache = None
+        self._flat = None          # training path: one fp32 buffer every nn.Parameter aliases (see _flat_sync)
+        self._flat_meta = None
+        self._live = _LivePack()
         if plot:
             print(f"Total Number of train params = {self.get_num_total_params()}")
 
     # ------------------------------------------------------------------ accessors (SCENE_Net.py:299-319)
     def get_cvx_coefficients(self):
+        object.__setattr__(self.lambdas_dict, "_sn_live", self._live)
         return self.lambdas_dict
 
     def get_num_total_params(self):
@@ -107,8 +155,10 @@ class SceneNet(nn.Module):
         return {name: param for name, param in self.named_parameters()}
 
     def get_geneo_params(self):
-        return nn.ParameterDict(dict([(name.replace(".", "_"), p) for name, p in self.named_parameters()
-                                      if "lambda" not in name]))
+        d = nn.ParameterDict(dict([(name.replace(".", "_"), p) for name, p in self.named_parameters()
+                                   if "lambda" not in name]))
+        object.__setattr__(d, "_sn_live", self._live)
+        return d
 
     def get_model_parameters_in_dict(self):
         ddd = {}
@@ -171,36 +221,56 @@ class SceneNet(nn.Module):
         return _hip.geneo_bank(params, kinds, self.kernel_size_of_bank())
 
     # ------------------------------------------------------------------ differentiable host logic (training)
-    def _packed_params_autograd(self, device) -> torch.Tensor:
-        """[G, SN_NPARAM] f32 stacked out of the nn.Parameters themselves, so autograd routes the HIP
-        generator Jacobians (sn_geneo_bank_bwd) back to every scalar."""
-        self.packed_params(device)  # validation (mandatory parameters, apex range) + kinds cache
-        zero = torch.zeros((), dtype=torch.float32, device=device)
-        rows = []
-        for layer in self.geneos.values():
-            kind, gp = layer.geneo_class.KIND, layer.geneo_params
-            slots = [zero] * _hip.SN_NPARAM
-            on = lambda t: t.to(device=device, dtype=torch.float32)  # noqa: E731
-            slots[_hip.SN_P_RADIUS] = on(gp["radius"])
-            slots[_hip.SN_P_SIGMA] = on(gp["sigma"]) if "sigma" in gp else zero + 1.0
-            if kind in (_hip.SN_GENEO_CONE, _hip.SN_GENEO_CONE_V1):
-                slots[_hip.SN_P_APEX] = on(gp["apex"]).detach()
-                slots[_hip.SN_P_CONE_RADIUS] = on(gp["cone_radius"])
-                slots[_hip.SN_P_CONE_INC] = on(gp["cone_inc"])
-            elif kind in (_hip.SN_GENEO_NEG, _hip.SN_GENEO_NEG_V1):
-                slots[_hip.SN_P_NEG_FACTOR] = on(gp["neg_factor"])
-            rows.append(torch.stack(slots))
-        return torch.stack(rows)
+    def _leaf_slots(self):
+        """[(nn.Parameter, slot)]: GENEO g's parameters at g*SN_NPARAM + slot, coefficient g at G*SN_NPARAM + g."""
+        G = len(self.geneos)
+        leaves = []
+        for g, layer in enumerate(self.geneos.values()):
+            for name, p in layer.geneo_params.items():
+                if name not in _SLOT_OF:
+                    raise KeyError(f"GENEO {layer.name}: unknown parameter {name}")
+                leaves.append((p, g * _hip.SN_NPARAM + _SLOT_OF[name]))
+        for g, n in enumerate(self.geneos):
+            leaves.append((self.lambdas_dict[f"lambda_{n}"], G * _hip.SN_NPARAM + g))
+        return leaves
 
-    def _effective_lambdas_autograd(self, device) -> torch.Tensor:
-        """SCENE_Net.py:329-335 with the graph kept: the last coefficient is 1 - sum(others), so its gradient
-        flows (negated) into every other lambda, exactly as in the reference."""
-        last = 1 - sum(self.lambdas_dict.values()) + self.lambdas_dict[self.last_lambda]
-        vals = [last if f"lambda_{g}" == self.last_lambda else self.lambdas_dict[f"lambda_{g}"] for g in self.geneos]
-        lam = torch.stack(vals).to(device=device, dtype=torch.float32)
-        self.lambdas_dict[self.last_lambda] = nn.Parameter(last.detach(), requires_grad=False)  # SCENE_Net.py:333
-        self._lambda_cache = None
-        return lam
+    def _flat_sync(self, device):
+        """One fp32 device buffer [G*SN_NPARAM + G] that every nn.Parameter of the model aliases (p.data is a 0-dim
+        view of its slot), so packing for the kernels costs nothing and an optimiser step updates the buffer in
+        place.  Re-established (one stack + one scatter) whenever something replaced a parameter's storage
+        (.to(), a fresh last-lambda Parameter from the inference path, ...)."""
+        leaves = self._leaf_slots()
+        flat = self._flat
+        ok = flat is not None and flat.device == device
+        if ok:
+            base = flat.data_ptr()
+            ok = all(p.data_ptr() == base + 4 * i and p.dtype == torch.float32 for p, i in leaves)
+        if ok and self._flat_meta["last_lambda"] == self.last_lambda:
+            return flat, self._flat_meta, leaves
+        self.packed_params(device)  # validation: mandatory parameters, apex range (cached on parameter versions)
+        G = len(self.geneos)
+        vals = torch.stack([p.detach().to(device=device, dtype=torch.float32) for p, _ in leaves])
+        flat = torch.zeros(G * _hip.SN_NPARAM + G, dtype=torch.float32, device=device)
+        flat[torch.arange(G, device=device) * _hip.SN_NPARAM + _hip.SN_P_SIGMA] = 1.0  # default sigma = 1
+        slots = torch.tensor([i for _, i in leaves], dtype=torch.int64, device=device)
+        flat[slots] = vals
+        for p, i in leaves:
+            p.data = flat[i]
+        names = list(self.geneos)
+        order = sorted(range(G), key=lambda i: f"lambda_{names[i]}")  # nn.ParameterDict order (sorted names)
+        last = names.index(self.last_lambda.replace("lambda_", "", 1))
+        n_geneo = len(leaves) - G
+        self._flat = flat
+        self._flat_meta = {
+            "last_lambda": self.last_lambda, "last": last, "G": G,
+            "order": torch.tensor(order, dtype=torch.int32, device=device),
+            "kinds": torch.tensor([l.geneo_class.KIND for l in self.geneos.values()], dtype=torch.int32, device=device),
+            "slots": tuple(i for _, i in leaves),
+            "param_idx": slots[:n_geneo].clone(),
+            "free_idx": torch.tensor([G * _hip.SN_NPARAM + g for g in range(G) if g != last], dtype=torch.int64,
+                                     device=device),
+        }
+        return flat, self._flat_meta, leaves
 
     def forward(self, x: torch.Tensor, return_bank_activations: bool = False):
         """x [B,1,Z,X,Y] on a HIP device -> relu(tanh(sum_i lambda_i conv3d(x, K_i))) [B,1,Z,X,Y], same dtype
@@ -211,10 +281,15 @@ class SceneNet(nn.Module):
             raise _hip.HipLibraryError("SceneNet.forward runs on the HIP device only (no CPU fallback): move x to cuda")
         ks = self.kernel_size_of_bank()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            params = self._packed_params_autograd(x.device)
-            lam = self._effective_lambdas_autograd(x.device)
-            kinds = self.packed_params(x.device)[1]
-            out, act = _GeneoForwardFn.apply(x.contiguous(), params, lam, kinds, ks, return_bank_activations)
+            flat, meta, leaves = self._flat_sync(x.device)
+            params = [p for p, _ in leaves]
+            P = _GatherParamsFn.apply(flat, meta["slots"], *params)
+            live = self._live
+            live.packed, live.leaves = P, tuple(params)
+            live.param_idx, live.free_idx = meta["param_idx"], meta["free_idx"]
+            out, act = _GeneoForwardFn.apply(x.contiguous(), P, flat, meta, ks, return_bank_activations)
+            live.versions = tuple(p._version for p in params)
+            self._lambda_cache = None  # lambdas_dict[last_lambda] was refreshed in place (SCENE_Net.py:333)
             return (out, act) if return_bank_activations else out
         with torch.no_grad():
             bank = self.compute_bank(x.device)
@@ -226,32 +301,41 @@ class SceneNet(nn.Module):
 
 
 class _GeneoForwardFn(torch.autograd.Function):
-    """K2 + K3 forward, (sn_conv_corr, sn_geneo_bank_bwd) backward.  Inputs with gradients: params [G,8], lam [G]."""
+    """K2 + K3 forward, (sn_conv_corr, sn_geneo_bank_bwd) backward.  P [G*SN_NPARAM + G] is the gathered parameter
+    vector (the gradient target); values are read from `flat`, the buffer the nn.Parameters alias, whose frozen
+    coefficient sn_effective_lambdas refreshes in place."""
 
     @staticmethod
-    def forward(ctx, x, params, lam, kinds, kernel_size, want_act):
-        p = params.detach().contiguous()
-        l = lam.detach().contiguous()
-        bank = _hip.geneo_bank(p, kinds, kernel_size)
+    def forward(ctx, x, P, flat, meta, kernel_size, want_act):
+        G = meta["G"]
+        n = G * _hip.SN_NPARAM
+        p = flat[:n].view(G, _hip.SN_NPARAM)
+        lam = _hip.effective_lambdas(flat[n:], meta["order"], meta["last"])
+        bank = _hip.geneo_bank(p, meta["kinds"], kernel_size)
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
-        act, out = _hip.conv_bank(x, bank, l, want_act=want_act, want_out=True, out_dtype=out_dtype)
-        ctx.save_for_backward(x, out, bank, p, l, kinds)
+        act, out = _hip.conv_bank(x, bank, lam, want_act=want_act, want_out=True, out_dtype=out_dtype)
+        ctx.save_for_backward(x, out, bank, P, lam, meta["kinds"])
         ctx.kernel_size = tuple(kernel_size)
+        ctx.G, ctx.last = G, meta["last"]
         if act is not None:
             ctx.mark_non_differentiable(act)
         return out, act
 
     @staticmethod
     def backward(ctx, gout, _gact=None):
-        x, out, bank, p, l, kinds = ctx.saved_tensors
-        G = bank.shape[0]
+        x, out, bank, P, lam, kinds = ctx.saved_tensors
+        G = ctx.G
+        n = G * _hip.SN_NPARAM
         C = _hip.conv_corr(x, gout.to(torch.float32).contiguous(), out.to(torch.float32).contiguous(),
                            ctx.kernel_size)                      # [kz,kx,ky]
         c = C.reshape(1, -1)
-        dlam = (bank.reshape(G, -1) * c).sum(dim=1)              # dL/dlambda_g = <K_g, C>
-        dW = (l.reshape(G, 1) * c).reshape(bank.shape).contiguous()  # dL/dK_g = lambda_g C
-        dparams = _hip.geneo_bank_bwd(p, kinds, ctx.kernel_size, dW)
-        return None, dparams, dlam, None, None, None
+        gP = torch.empty_like(P)
+        dlam = torch.mv(bank.reshape(G, -1), c.reshape(-1))      # dL/dlambda_g(effective) = <K_g, C>
+        # lambda_last = 1 - sum(others): its gradient flows, negated, into every other coefficient (SCENE_Net.py:331)
+        torch.sub(dlam, dlam[ctx.last], out=gP[n:])
+        dW = (lam.reshape(G, 1) * c).reshape(bank.shape)         # dL/dK_g = lambda_g C
+        gP[:n] = _hip.geneo_bank_bwd(P[:n].view(G, _hip.SN_NPARAM), kinds, ctx.kernel_size, dW).reshape(-1)
+        return None, gP, None, None, None, None
 
 
 class SCENE_Net(SceneNet):
