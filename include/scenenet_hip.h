@@ -251,6 +251,14 @@ int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dty
                     double dice_smooth, double* parts_ws, double* stats, double* loss, double* coef,
                     sn_stream_t stream);
 
+/* The penalties of GENEO_Loss over the model's scalars (core/criterions/geneo_loss.py:36-70) in one launch:
+ * value[0] = weight * ( sum_{mask[i] >= 1} relu(-P[i]) + [with_sum] relu(-(1 - sum_{mask[i] == 2} P[i])) ),
+ * grad[i] = d value / d P[i].  P [N] f32 (the packed parameter vector), mask [N] i8: 0 = not a parameter,
+ * 1 = GENEO parameter (positive_regularizer), 2 = trainable convex coefficient (cvx_loss: its own relu(-phi) and the
+ * relu(-(1 - sum)) of the frozen last one). */
+int sn_param_penalty(const float* P, const int8_t* mask, int N, float weight, int with_sum, float* value, float* grad,
+                     sn_stream_t stream);
+
 /* Backward: grad_pred[b,i] = up * (coef[bin(gt)] (p - t) + A_b t + B_b + C_b p), in pred's dtype.
  * upstream: device scalar f64 (dL/dloss), NULL = 1. */
 int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,

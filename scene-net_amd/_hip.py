@@ -45,6 +45,7 @@ SYMBOLS = {
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_loss_forward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
                         + [_P, _P, _P, _P, _P]),
+    "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
     "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
 }
 SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE = 1, 2, 4
@@ -361,3 +362,14 @@ def loss_backward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, co
                                  _ptr(grad), _stream())
     _check(rc, "sn_loss_backward")
     return grad
+
+
+def param_penalty(P: torch.Tensor, mask: torch.Tensor, weight: float, with_sum: bool):
+    """sn_param_penalty: (value [1] f32, grad [N] f32) of the GENEO_Loss penalties over the packed parameters."""
+    N = int(P.numel())
+    value = torch.empty((1,), dtype=torch.float32, device=P.device)
+    grad = torch.empty((N,), dtype=torch.float32, device=P.device)
+    rc = load().sn_param_penalty(_ptr(P, torch.float32, "P"), _ptr(mask, torch.int8, "mask"), N, float(weight),
+                                 int(bool(with_sum)), _ptr(value), _ptr(grad), _stream())
+    _check(rc, "sn_param_penalty")
+    return value, grad

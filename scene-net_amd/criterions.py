@@ -62,6 +62,21 @@ def _dense_loss(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_
     return loss
 
 
+class _PenaltyFn(torch.autograd.Function):
+    """geneo_loss.py:36-70 over the packed parameter vector (sn_param_penalty): value and gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, P, mask, weight, with_sum):
+        value, grad = _hip.param_penalty(P.detach().contiguous(), mask, weight, with_sum)
+        ctx.save_for_backward(grad)
+        return value.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
 def _live_pack(container):
     """(P, live) when `container` came from a scene_net_amd model whose latest differentiable forward gathered its
     parameters into one vector P that is still current (scene_net._LivePack), else (None, None)."""
@@ -266,11 +281,10 @@ class GENEO_Loss(WeightedMSE):
         if len(cvx_coeffs) == 0:
             return 0
         P, live = _live_pack(cvx_coeffs)
-        if P is not None:   # the model's gathered parameter vector: one autograd node for all scalars
-            free = P.index_select(0, live.free_idx)
-        else:
-            last_phi = [n for n in cvx_coeffs if not cvx_coeffs[n].requires_grad][0]
-            free = torch.stack([phi for n, phi in cvx_coeffs.items() if n != last_phi])
+        if P is not None:   # the model's gathered parameter vector: one launch, one autograd node
+            return _PenaltyFn.apply(P, live.mask_cvx, self.cvx_w, True)
+        last_phi = [n for n in cvx_coeffs if not cvx_coeffs[n].requires_grad][0]
+        free = torch.stack([phi for n, phi in cvx_coeffs.items() if n != last_phi])
         return self.cvx_w * (torch.relu(-free).sum() + torch.relu(-(1 - free.sum())))
 
     def positive_regularizer(self, params):
@@ -278,8 +292,17 @@ class GENEO_Loss(WeightedMSE):
         if len(params) == 0:
             return 0
         P, live = _live_pack(params)
-        vals = P.index_select(0, live.param_idx) if P is not None else torch.stack(list(params.values()))
-        return self.cvx_w * torch.relu(-vals).sum()
+        if P is not None:
+            return _PenaltyFn.apply(P, live.mask_params, self.cvx_w, False)
+        return self.cvx_w * torch.relu(-torch.stack(list(params.values()))).sum()
+
+    def _penalties(self, cvx_coeffs, geneo_params):
+        """cvx_loss + positive_regularizer; one launch when both come from the same live scene_net_amd model."""
+        Pc, live = _live_pack(cvx_coeffs)
+        Pp, live_p = _live_pack(geneo_params)
+        if Pc is not None and Pp is Pc and len(cvx_coeffs) and len(geneo_params):
+            return _PenaltyFn.apply(Pc, live.mask_all, self.cvx_w, True)
+        return self.cvx_loss(cvx_coeffs) + self.positive_regularizer(geneo_params)
 
     def _terms(self):
         return _hip.SN_LOSS_WMSE, {}
@@ -287,7 +310,7 @@ class GENEO_Loss(WeightedMSE):
     def forward(self, y_pred, y_gt, cvx_coeffs, geneo_params):
         terms, cfg = self._terms()
         dense_criterion = self._dense(y_pred, y_gt, terms, **cfg)
-        return dense_criterion + self.cvx_loss(cvx_coeffs) + self.positive_regularizer(geneo_params)
+        return dense_criterion + self._penalties(cvx_coeffs, geneo_params)
 
     def __str__(self):
         return f"GENEO Loss with mse_weight={self.mse_weight} and alpha={self.weight_alpha} and epsilon={self.weight_epsilon}"

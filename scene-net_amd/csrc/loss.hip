@@ -88,62 +88,101 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ---------------------------------------------------------------- pass 1: partial statistics
 // grid = (parts, B); block `part` owns elements [part*span, (part+1)*span) of sample b (span a multiple of 4).
-template <typename PT, typename GT>
+// kBinary (gt is SN_OCC8, values in {0,1}): two classes, everything in registers (~10 VALU per element).
+// Otherwise: per-thread per-bin accumulators live in LDS ([bin][thread], conflict free) -- register accumulators
+// would cost a 16-way select per element and make the pass VALU-bound; byte targets find their bin in a 256-entry
+// LDS table, float targets by the first-minimum search of the reference.
+template <typename GT>
+__device__ __forceinline__ int bin_lookup(const BinOf<GT>& bin, const int* lut, GT tv) {
+    if constexpr (sizeof(GT) == 1) return lut[tv];
+    else return bin(tv);
+}
+
+template <typename PT, typename GT, bool kBinary>
 __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restrict__ pred, const GT* __restrict__ gt,
                                                               long n_per, long span, const float* __restrict__ ranges,
                                                               int H, double* __restrict__ parts) {
     __shared__ double red[kThreads / 64][2 * kMaxBins + 5];
-    const int part = blockIdx.x, b = blockIdx.y, nparts = gridDim.x;
+    __shared__ double sq_l[kBinary ? 1 : kMaxBins * kThreads];
+    __shared__ int cnt_l[kBinary ? 1 : kMaxBins * kThreads];
+    __shared__ int lut[256];
+    const int part = blockIdx.x, b = blockIdx.y, nparts = gridDim.x, tid = threadIdx.x;
     const long lo = (long)part * span, hi = (lo + span < n_per) ? lo + span : n_per;
     const PT* p = pred + (size_t)b * n_per;
     const GT* t = gt + (size_t)b * n_per;
     BinOf<GT> bin;
     bin.init(ranges, H);
-
-    double cnt[kMaxBins], sq[kMaxBins];
-#pragma unroll
-    for (int k = 0; k < kMaxBins; ++k) cnt[k] = 0.0, sq[k] = 0.0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nstat = 2 * H + 5;
     double s_pt = 0, s_p = 0, s_t = 0, s_pp = 0, s_tt = 0;
+    const bool vec = (n_per % 4 == 0);  // the sample base is then 4-element aligned (host checks the pointers)
 
-    auto take = [&](PT pv, GT tv) {
-        const double pd = (double)pv, td = (double)tv;
-        const double e = td - pd;
-        const int k = bin(tv);
+    if constexpr (kBinary) {
+        double sq_all = 0, sq1 = 0;
+        int n_all = 0, n1 = 0;
+        auto take = [&](PT pv, GT tv) {
+            const double pd = (double)pv;
+            const bool one = tv != 0;
+            const double e = (one ? 1.0 : 0.0) - pd, e2 = e * e;
+            n_all += 1;
+            n1 += one ? 1 : 0;
+            sq_all += e2;
+            sq1 += one ? e2 : 0.0;
+            s_pt += one ? pd : 0.0;
+            s_p += pd;
+            s_pp += pd * pd;
+        };
+        if (vec) {
+            for (long i = lo + 4 * (long)tid; i + 3 < hi; i += 4 * kThreads) {
+                const Vec4<PT> pv = load4(p + i);
+                const Vec4<GT> tv = load4(t + i);
 #pragma unroll
-        for (int j = 0; j < kMaxBins; ++j) {
-            const bool m = (j == k);
-            cnt[j] += m ? 1.0 : 0.0;
-            sq[j] += m ? e * e : 0.0;
+                for (int j = 0; j < 4; ++j) take(pv.v[j], tv.v[j]);
+            }
+        } else {
+            for (long i = lo + tid; i < hi; i += kThreads) take(p[i], t[i]);
         }
-        s_pt += pd * td;
-        s_p += pd;
-        s_t += td;
-        s_pp += pd * pd;
-        s_tt += td * td;
-    };
-
-    // vector body: the sample base is 4-element aligned when n_per % 4 == 0 (host checks pointer alignment)
-    const bool vec = (n_per % 4 == 0);
-    if (vec) {
-        for (long i = lo + 4 * (long)threadIdx.x; i + 3 < hi; i += 4 * kThreads) {
-            const Vec4<PT> pv = load4(p + i);
-            const Vec4<GT> tv = load4(t + i);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) take(pv.v[j], tv.v[j]);
+        const int b0 = bin((GT)0), b1 = bin((GT)1);
+        const double c1 = wave_sum((double)n1), c0 = wave_sum((double)(n_all - n1));
+        const double q1 = wave_sum(sq1), q0 = wave_sum(sq_all - sq1);
+        const double a = wave_sum(s_pt), c = wave_sum(s_p), e = wave_sum(s_pp);
+        if (lane == 0) {
+            for (int j = 0; j < 2 * H; ++j) red[wave][j] = 0.0;
+            red[wave][b0] += c0; red[wave][b1] += c1;
+            red[wave][H + b0] += q0; red[wave][H + b1] += q1;
+            red[wave][2 * H + 0] = a; red[wave][2 * H + 1] = c; red[wave][2 * H + 2] = c1;
+            red[wave][2 * H + 3] = e; red[wave][2 * H + 4] = c1;
         }
     } else {
-        for (long i = lo + threadIdx.x; i < hi; i += kThreads) take(p[i], t[i]);
-    }
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nstat = 2 * H + 5;
-    for (int j = 0; j < kMaxBins; ++j) {
-        if (j < H) {
-            const double a = wave_sum(cnt[j]), c = wave_sum(sq[j]);
+        if constexpr (sizeof(GT) == 1) lut[tid] = bin((GT)tid);
+        for (int k = 0; k < H; ++k) sq_l[k * kThreads + tid] = 0.0, cnt_l[k * kThreads + tid] = 0;
+        __syncthreads();
+        auto take = [&](PT pv, GT tv) {
+            const double pd = (double)pv, td = (double)tv;
+            const double e = td - pd;
+            const int k = bin_lookup(bin, lut, tv) * kThreads + tid;
+            sq_l[k] += e * e;
+            cnt_l[k] += 1;
+            s_pt += pd * td;
+            s_p += pd;
+            s_t += td;
+            s_pp += pd * pd;
+            s_tt += td * td;
+        };
+        if (vec) {
+            for (long i = lo + 4 * (long)tid; i + 3 < hi; i += 4 * kThreads) {
+                const Vec4<PT> pv = load4(p + i);
+                const Vec4<GT> tv = load4(t + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) take(pv.v[j], tv.v[j]);
+            }
+        } else {
+            for (long i = lo + tid; i < hi; i += kThreads) take(p[i], t[i]);
+        }
+        for (int j = 0; j < H; ++j) {
+            const double a = wave_sum((double)cnt_l[j * kThreads + tid]), c = wave_sum(sq_l[j * kThreads + tid]);
             if (lane == 0) red[wave][j] = a, red[wave][H + j] = c;
         }
-    }
-    {
         const double a = wave_sum(s_pt), c = wave_sum(s_p), d = wave_sum(s_t), e = wave_sum(s_pp), f = wave_sum(s_tt);
         if (lane == 0) {
             red[wave][2 * H + 0] = a; red[wave][2 * H + 1] = c; red[wave][2 * H + 2] = d;
@@ -151,10 +190,10 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
         }
     }
     __syncthreads();
-    if (threadIdx.x < nstat) {
+    if (tid < nstat) {
         double s = 0;
-        for (int w = 0; w < kThreads / 64; ++w) s += red[w][threadIdx.x];
-        parts[((size_t)b * nparts + part) * nstat + threadIdx.x] = s;
+        for (int w = 0; w < kThreads / 64; ++w) s += red[w][tid];
+        parts[((size_t)b * nparts + part) * nstat + tid] = s;
     }
 }
 
@@ -173,14 +212,31 @@ __global__ __launch_bounds__(kThreads) void loss_combine_kernel(const double* __
     const int nstat = 2 * H + 5;
     for (int i = threadIdx.x; i < B * nstat; i += kThreads) {
         const int b = i / nstat, j = i % nstat;
+        const double* src = parts + (size_t)b * nparts * nstat + j;
         double s = 0;
-        for (int q = 0; q < nparts; ++q) s += parts[((size_t)b * nparts + q) * nstat + j];
+        int q = 0;
+        for (; q + 8 <= nparts; q += 8) {   // eight independent loads in flight, summed in order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(q + u) * nstat];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; q < nparts; ++q) s += src[(size_t)q * nstat];
         stats[i] = s;
     }
     __syncthreads();  // stats[] written by this block is visible to it after the barrier
     if (threadIdx.x < nstat) {
         double s = 0;
-        for (int b = 0; b < B; ++b) s += stats[(size_t)b * nstat + threadIdx.x];
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = stats[(size_t)(b + u) * nstat + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < B; ++b) s += stats[(size_t)b * nstat + threadIdx.x];
         tot[threadIdx.x] = s;
     }
     // dice, per sample (dice_loss.py:38-41), mean over the batch; gradient coefficients per sample
@@ -243,14 +299,16 @@ __global__ __launch_bounds__(kThreads) void loss_combine_kernel(const double* __
 }
 
 // ---------------------------------------------------------------- pass 2: dL/dpred
-template <typename PT, typename GT>
+template <typename PT, typename GT, bool kBinary>
 __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restrict__ pred, const GT* __restrict__ gt,
                                                              long n_per, long span, const float* __restrict__ ranges,
                                                              int H, const double* __restrict__ coef,
                                                              const double* __restrict__ upstream,
                                                              PT* __restrict__ grad) {
     using C = PT;  // gradient arithmetic in pred's dtype
-    const int part = blockIdx.x, b = blockIdx.y;
+    __shared__ C ck[kMaxBins];
+    __shared__ int lut[256];
+    const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const long lo = (long)part * span, hi = (lo + span < n_per) ? lo + span : n_per;
     const PT* p = pred + (size_t)b * n_per;
     const GT* t = gt + (size_t)b * n_per;
@@ -258,21 +316,29 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
     BinOf<GT> bin;
     bin.init(ranges, H);
     const double up = upstream ? *upstream : 1.0;
-    C ck[kMaxBins];
-#pragma unroll
-    for (int k = 0; k < kMaxBins; ++k) ck[k] = (C)(coef[k] * up);
     const C A = (C)(coef[kMaxBins + 3 * b] * up), Bc = (C)(coef[kMaxBins + 3 * b + 1] * up),
             Cc = (C)(coef[kMaxBins + 3 * b + 2] * up);
+    C c0 = 0, c1 = 0;
+    if constexpr (kBinary) {
+        c0 = (C)(coef[bin((GT)0)] * up);
+        c1 = (C)(coef[bin((GT)1)] * up);
+    } else {
+        if (tid < kMaxBins) ck[tid] = (C)(coef[tid] * up);
+        if constexpr (sizeof(GT) == 1) lut[tid] = bin((GT)tid);
+        __syncthreads();
+    }
     auto one = [&](PT pv, GT tv) -> PT {
-        const int k = bin(tv);
-        C c = ck[0];
-#pragma unroll
-        for (int j = 1; j < kMaxBins; ++j) c = (j == k) ? ck[j] : c;
-        const C pc = (C)pv, tc = (C)tv;
-        return (PT)(c * (pc - tc) + A * tc + Bc + Cc * pc);
+        const C pc = (C)pv;
+        if constexpr (kBinary) {
+            // t in {0,1}:  c (p - t) + A t + B + C p
+            return (tv != 0) ? (PT)(c1 * (pc - (C)1) + A + Bc + Cc * pc) : (PT)(c0 * pc + Bc + Cc * pc);
+        } else {
+            const C c = ck[bin_lookup(bin, lut, tv)], tc = (C)tv;
+            return (PT)(c * (pc - tc) + A * tc + Bc + Cc * pc);
+        }
     };
     if (n_per % 4 == 0) {
-        for (long i = lo + 4 * (long)threadIdx.x; i + 3 < hi; i += 4 * kThreads) {
+        for (long i = lo + 4 * (long)tid; i + 3 < hi; i += 4 * kThreads) {
             const Vec4<PT> pv = load4(p + i);
             const Vec4<GT> tv = load4(t + i);
             Vec4<PT> r;
@@ -281,8 +347,32 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
             store4(g + i, r);
         }
     } else {
-        for (long i = lo + threadIdx.x; i < hi; i += kThreads) g[i] = one(p[i], t[i]);
+        for (long i = lo + tid; i < hi; i += kThreads) g[i] = one(p[i], t[i]);
     }
+}
+
+// ---------------------------------------------------------------- penalties over the ~50 scalars
+// geneo_loss.py:36-70 in one launch: value = w * ( sum_{mask>=1} relu(-v) + relu(-(1 - sum_{mask==2} v)) ) and its
+// gradient.  Sequential fp32 sums by one thread (slot order).
+__global__ void param_penalty_kernel(const float* __restrict__ P, const int8_t* __restrict__ mask, int N, float w,
+                                     int with_sum, float* __restrict__ value, float* __restrict__ grad) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float pen = 0.f, free_sum = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const float v = P[i];
+        if (mask[i] >= 1) pen += fmaxf(-v, 0.f);
+        if (mask[i] == 2) free_sum += v;
+    }
+    const float last = 1.f - free_sum;             // the frozen coefficient, 1 - sum(others)
+    const bool last_neg = with_sum && (last < 0.f);
+    if (last_neg) pen += -last;
+    for (int i = 0; i < N; ++i) {
+        float g = 0.f;
+        if (mask[i] >= 1 && P[i] < 0.f) g -= 1.f;  // d relu(-v)/dv
+        if (mask[i] == 2 && last_neg) g += 1.f;    // d relu(-(1 - sum))/dv
+        grad[i] = w * g;
+    }
+    value[0] = w * pen;
 }
 
 int check_common(const char* fn, const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
@@ -308,16 +398,18 @@ long span_of(int64_t n_per, int nparts) {
 
 }  // namespace
 
-#define SN_LOSS_DISPATCH(KERNEL, ...)                                                                             \
+#define SN_LOSS_DISPATCH(KERNEL)                                                                                  \
     do {                                                                                                          \
         if (pred_dtype == SN_F32) {                                                                               \
-            if (gt_dtype == SN_F32) KERNEL(float, float, __VA_ARGS__);                                            \
-            else if (gt_dtype == SN_F64) KERNEL(float, double, __VA_ARGS__);                                      \
-            else KERNEL(float, uint8_t, __VA_ARGS__);                                                             \
+            if (gt_dtype == SN_F32) KERNEL(float, float, false);                                                  \
+            else if (gt_dtype == SN_F64) KERNEL(float, double, false);                                            \
+            else if (gt_dtype == SN_OCC8) KERNEL(float, uint8_t, true);                                           \
+            else KERNEL(float, uint8_t, false);                                                                   \
         } else {                                                                                                  \
-            if (gt_dtype == SN_F32) KERNEL(double, float, __VA_ARGS__);                                           \
-            else if (gt_dtype == SN_F64) KERNEL(double, double, __VA_ARGS__);                                     \
-            else KERNEL(double, uint8_t, __VA_ARGS__);                                                            \
+            if (gt_dtype == SN_F32) KERNEL(double, float, false);                                                 \
+            else if (gt_dtype == SN_F64) KERNEL(double, double, false);                                           \
+            else if (gt_dtype == SN_OCC8) KERNEL(double, uint8_t, true);                                          \
+            else KERNEL(double, uint8_t, false);                                                                  \
         }                                                                                                         \
     } while (0)
 
@@ -335,16 +427,25 @@ extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt,
     hipStream_t s = sn::as_stream(stream);
     const int nparts = SN_LOSS_PARTS(n_per);
     const long span = span_of(n_per, nparts);
-#define SN_STATS(PT, GT, ...)                                                                                     \
-    hipLaunchKernelGGL((loss_stats_kernel<PT, GT>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,       \
+#define SN_STATS(PT, GT, BIN)                                                                                     \
+    hipLaunchKernelGGL((loss_stats_kernel<PT, GT, BIN>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,  \
                        (const GT*)gt, (long)n_per, span, ranges, H, parts_ws)
-    SN_LOSS_DISPATCH(SN_STATS, 0);
+    SN_LOSS_DISPATCH(SN_STATS);
 #undef SN_STATS
     if (int rc = sn::check_launch("sn_loss_forward(stats)")) return rc;
     LossCfg cfg{terms, mse_weight, tversky_alpha, tversky_beta, focal_gamma, tversky_smooth, dice_smooth};
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kThreads), 0, s, parts_ws, B, nparts, (long)n_per, H, bin_w,
                        cfg, stats, loss, coef);
     return sn::check_launch("sn_loss_forward(combine)");
+}
+
+extern "C" int sn_param_penalty(const float* P, const int8_t* mask, int N, float weight, int with_sum, float* value,
+                                float* grad, sn_stream_t stream) {
+    if (!P || !mask || !value || !grad) return sn::fail(SN_ERR_INVALID_ARG, "sn_param_penalty: null pointer");
+    if (N <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_param_penalty: N must be positive");
+    hipLaunchKernelGGL(param_penalty_kernel, dim3(1), dim3(64), 0, sn::as_stream(stream), P, mask, N, weight, with_sum,
+                       value, grad);
+    return sn::check_launch("sn_param_penalty");
 }
 
 extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
@@ -358,10 +459,10 @@ extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt
     hipStream_t s = sn::as_stream(stream);
     const int nparts = SN_LOSS_PARTS(n_per);
     const long span = span_of(n_per, nparts);
-#define SN_GRAD(PT, GT, ...)                                                                                      \
-    hipLaunchKernelGGL((loss_grad_kernel<PT, GT>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,        \
+#define SN_GRAD(PT, GT, BIN)                                                                                      \
+    hipLaunchKernelGGL((loss_grad_kernel<PT, GT, BIN>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,   \
                        (const GT*)gt, (long)n_per, span, ranges, H, coef, upstream, (PT*)grad_pred)
-    SN_LOSS_DISPATCH(SN_GRAD, 0);
+    SN_LOSS_DISPATCH(SN_GRAD);
 #undef SN_GRAD
     return sn::check_launch("sn_loss_backward");
 }

@@ -29,8 +29,9 @@ class _LivePack:
         self.packed = None        # P [G*SN_NPARAM + G] f32, non-leaf
         self.versions = None      # parameter versions P was gathered at
         self.leaves = ()          # the nn.Parameters, in slot order
-        self.param_idx = None     # device int64: slots that hold a GENEO parameter
-        self.free_idx = None      # device int64: slots of the trainable convex coefficients
+        self.mask_params = None   # device int8 [N]: 1 on slots that hold a GENEO parameter
+        self.mask_cvx = None      # device int8 [N]: 2 on slots of the trainable convex coefficients
+        self.mask_all = None      # both
 
     def current(self):
         """P if no parameter changed since it was gathered, else None."""
@@ -56,7 +57,8 @@ class _GatherParamsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gP):
-        grads = tuple(gP[i] if need else None for i, need in zip(ctx.slots, ctx.needs_input_grad[2:]))
+        cols = gP.unbind(0)  # one call, N zero-dim views
+        grads = tuple(cols[i] if need else None for i, need in zip(ctx.slots, ctx.needs_input_grad[2:]))
         return (None, None) + grads
 
 
@@ -154,10 +156,19 @@ class SceneNet(nn.Module):
             return {name: param.detach().clone() for name, param in self.named_parameters()}
         return {name: param for name, param in self.named_parameters()}
 
+    def _geneo_leaves(self):
+        """The GENEO nn.Parameters in ModuleDict order (identity tuple: cheap to compare between calls)."""
+        return tuple(p for layer in self.geneos.values() for p in layer.geneo_params._parameters.values())
+
     def get_geneo_params(self):
+        leaves = self._geneo_leaves()
+        cached = self.__dict__.get("_geneo_params_cache")
+        if cached is not None and len(cached[0]) == len(leaves) and all(a is b for a, b in zip(cached[0], leaves)):
+            return cached[1]   # same Parameter objects as last time: same dict (the reference rebuilds it per call)
         d = nn.ParameterDict(dict([(name.replace(".", "_"), p) for name, p in self.named_parameters()
                                    if "lambda" not in name]))
         object.__setattr__(d, "_sn_live", self._live)
+        self.__dict__["_geneo_params_cache"] = (leaves, d)
         return d
 
     def get_model_parameters_in_dict(self):
@@ -239,14 +250,15 @@ class SceneNet(nn.Module):
         view of its slot), so packing for the kernels costs nothing and an optimiser step updates the buffer in
         place.  Re-established (one stack + one scatter) whenever something replaced a parameter's storage
         (.to(), a fresh last-lambda Parameter from the inference path, ...)."""
+        flat, meta = self._flat, self._flat_meta
+        if flat is not None and flat.device == device and meta["last_lambda"] == self.last_lambda:
+            # same Parameter objects (identity walk over the dicts), each still a view of its slot
+            current = self._geneo_leaves() + tuple(self.lambdas_dict._parameters[n] for n in meta["lambda_names"])
+            leaves, base = meta["leaves"], flat.data_ptr()
+            if len(current) == len(leaves) and all(
+                    a is p and p.data_ptr() == base + 4 * i for a, (p, i) in zip(current, leaves)):
+                return flat, meta, leaves
         leaves = self._leaf_slots()
-        flat = self._flat
-        ok = flat is not None and flat.device == device
-        if ok:
-            base = flat.data_ptr()
-            ok = all(p.data_ptr() == base + 4 * i and p.dtype == torch.float32 for p, i in leaves)
-        if ok and self._flat_meta["last_lambda"] == self.last_lambda:
-            return flat, self._flat_meta, leaves
         self.packed_params(device)  # validation: mandatory parameters, apex range (cached on parameter versions)
         G = len(self.geneos)
         vals = torch.stack([p.detach().to(device=device, dtype=torch.float32) for p, _ in leaves])
@@ -262,14 +274,17 @@ class SceneNet(nn.Module):
         n_geneo = len(leaves) - G
         self._flat = flat
         self._flat_meta = {
-            "last_lambda": self.last_lambda, "last": last, "G": G,
+            "last_lambda": self.last_lambda, "last": last, "G": G, "leaves": leaves,
+            "lambda_names": tuple(f"lambda_{n}" for n in names),
             "order": torch.tensor(order, dtype=torch.int32, device=device),
             "kinds": torch.tensor([l.geneo_class.KIND for l in self.geneos.values()], dtype=torch.int32, device=device),
             "slots": tuple(i for _, i in leaves),
-            "param_idx": slots[:n_geneo].clone(),
-            "free_idx": torch.tensor([G * _hip.SN_NPARAM + g for g in range(G) if g != last], dtype=torch.int64,
-                                     device=device),
         }
+        mp = torch.zeros(flat.numel(), dtype=torch.int8)
+        mp[[i for _, i in leaves[:n_geneo]]] = 1
+        mc = torch.zeros(flat.numel(), dtype=torch.int8)
+        mc[[G * _hip.SN_NPARAM + g for g in range(G) if g != last]] = 2
+        self._flat_meta.update(mask_params=mp.to(device), mask_cvx=mc.to(device), mask_all=(mp + mc).to(device))
         return flat, self._flat_meta, leaves
 
     def forward(self, x: torch.Tensor, return_bank_activations: bool = False):
@@ -286,7 +301,7 @@ class SceneNet(nn.Module):
             P = _GatherParamsFn.apply(flat, meta["slots"], *params)
             live = self._live
             live.packed, live.leaves = P, tuple(params)
-            live.param_idx, live.free_idx = meta["param_idx"], meta["free_idx"]
+            live.mask_params, live.mask_cvx, live.mask_all = meta["mask_params"], meta["mask_cvx"], meta["mask_all"]
             out, act = _GeneoForwardFn.apply(x.contiguous(), P, flat, meta, ks, return_bank_activations)
             live.versions = tuple(p._version for p in params)
             self._lambda_cache = None  # lambdas_dict[last_lambda] was refreshed in place (SCENE_Net.py:333)
