@@ -259,8 +259,7 @@ extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const
 #define SN_CORR(XT)                                                                                               \
     do {                                                                                                          \
         auto kern = corr_partial_kernel<XT>;                                                                      \
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=       \
-            hipSuccess)                                                                                           \
+        if (sn::ensure_dynamic_lds((const void*)kern, (int)lds) != hipSuccess)                                    \
             return sn::check_launch("sn_conv_corr(hipFuncSetAttribute)");                                         \
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(kThreads), lds, s, (const XT*)x, gout, out, B, Z, X, Y, kz, kx, \
                            ky, nzt, nxt, nyt, partial_ws);                                                        \

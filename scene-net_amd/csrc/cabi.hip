@@ -3,6 +3,8 @@
 #include <cstring>
 
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 namespace sn {
 char* error_buffer() {
@@ -11,6 +13,20 @@ char* error_buffer() {
 }
 static std::atomic<int> g_skip_empty{0};
 int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
+
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> configured;  // per process; one device kind (gfx950)
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void* key = (const char*)kernel + dev;  // attributes are per device
+    auto it = configured.find(key);
+    if (it != configured.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) configured[key] = bytes;
+    return e;
+}
 }  // namespace sn
 
 extern "C" int sn_set_option(const char* name, int value) {

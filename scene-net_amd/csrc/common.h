@@ -27,4 +27,8 @@ inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_
 
 int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per kernel (and raised when a launch needs more): the
+// attribute call is not a stream operation, so steady-state launches stay free of it (cheaper, graph-capturable).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);  // cabi.hip
+
 }  // namespace sn

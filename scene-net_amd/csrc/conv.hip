@@ -371,12 +371,8 @@ int launch(const void* x, const float* bank, const float* lambdas, const ConvSha
            hipStream_t stream) {
     auto kern = conv_bank_kernel<XT, OT, kDouble>;
     const size_t lds = lds_bytes(s, kDouble);
-    static thread_local const void* configured = nullptr;
-    if (configured != (const void*)kern) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess)
-            return sn::check_launch("sn_conv_bank(hipFuncSetAttribute)");
-        configured = (const void*)kern;
-    }
+    if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)
+        return sn::check_launch("sn_conv_bank(hipFuncSetAttribute)");
     int grid = num_cus();  // persistent: one workgroup per CU (LDS admits exactly one)
     if (grid > s.ntiles) grid = s.ntiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, (const XT*)x, bank, lambdas, s, (OT*)act,

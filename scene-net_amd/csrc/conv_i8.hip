@@ -568,8 +568,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
 #define SN_LAUNCH_I8(OT, YPBV, STG)                                                                              \
     do {                                                                                                         \
         auto kern = conv_occ_i8_kernel<OT, YPBV, STG>;                                                           \
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) !=       \
-            hipSuccess)                                                                                          \
+        if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
             return check_launch("sn_conv_bank(i8: hipFuncSetAttribute)");                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, ticket,           \
                            (OT*)act, (OT*)out);                                                                  \

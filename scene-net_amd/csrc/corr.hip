@@ -214,8 +214,7 @@ int sn::corr_mfma_launch(const void* x, int x_dtype, const float* gout, const fl
 #define SN_CORR_LAUNCH(XT, KZMAX)                                                                                 \
     do {                                                                                                          \
         auto kern = corr_mfma_kernel<XT, KZMAX>;                                                                  \
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=       \
-            hipSuccess)                                                                                           \
+        if (sn::ensure_dynamic_lds((const void*)kern, (int)lds) != hipSuccess)                                    \
             return sn::check_launch("sn_conv_corr(hipFuncSetAttribute)");                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, (const XT*)x, gout, out, s, partial_ws); \
     } while (0)

@@ -801,8 +801,7 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
     const bool al = aligned16(pts) && (!labels || aligned16(labels));
     {
         auto kern = al ? occ_partial_kernel<true> : occ_partial_kernel<false>;
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess)
+        if (sn::ensure_dynamic_lds((const void*)kern, 96 * 1024) != hipSuccess)
             return sn::check_launch("sn_voxel_occupancy(hipFuncSetAttribute)");
         hipLaunchKernelGGL(kern, dim3(parts * slabs, B), dim3(kOccThreads), lds1, s, pts, labels, offsets, desc, nx,
                            ny, nz, words, planes, parts, slabs, keep, bits_ws, dropped_parts, flags);

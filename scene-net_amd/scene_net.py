@@ -7,6 +7,7 @@ sn_geneo_bank (K2) and sn_conv_bank (K3, conv + convex head fused).  No CPU path
 """
 from __future__ import annotations
 
+import weakref
 from typing import Mapping, Optional, Tuple
 
 import torch
@@ -26,7 +27,7 @@ class _LivePack:
     accumulated ~50 times.  Never copied or pickled with the module."""
 
     def __init__(self):
-        self.packed = None        # P [G*SN_NPARAM + G] f32, non-leaf
+        self.packed = None        # weakref to P [G*SN_NPARAM + G] f32 (non-leaf): lives as long as that forward's graph
         self.versions = None      # parameter versions P was gathered at
         self.leaves = ()          # the nn.Parameters, in slot order
         self.mask_params = None   # device int8 [N]: 1 on slots that hold a GENEO parameter
@@ -35,9 +36,10 @@ class _LivePack:
 
     def current(self):
         """P if no parameter changed since it was gathered, else None."""
-        if self.packed is None or self.versions != tuple(p._version for p in self.leaves):
+        P = self.packed() if self.packed is not None else None
+        if P is None or self.versions != tuple(p._version for p in self.leaves):
             return None
-        return self.packed
+        return P
 
     def __deepcopy__(self, memo):
         return _LivePack()
@@ -300,7 +302,7 @@ class SceneNet(nn.Module):
             params = [p for p, _ in leaves]
             P = _GatherParamsFn.apply(flat, meta["slots"], *params)
             live = self._live
-            live.packed, live.leaves = P, tuple(params)
+            live.packed, live.leaves = weakref.ref(P), tuple(params)
             live.mask_params, live.mask_cvx, live.mask_all = meta["mask_params"], meta["mask_cvx"], meta["mask_all"]
             out, act = _GeneoForwardFn.apply(x.contiguous(), P, flat, meta, ks, return_bank_activations)
             live.versions = tuple(p._version for p in params)
