@@ -1,0 +1,190 @@
+"""Training-path plumbing on the MI355X: the flat parameter buffer behind the nn.Parameters, sn_effective_lambdas,
+sn_param_penalty, and whole-step hipGraph capture."""
+import copy
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from scene_net_amd import _hip
+from oracle import geneo_oracle as go
+from oracle import loss_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(dev, seed=3, ks=(9, 5, 5)):
+    torch.manual_seed(seed)
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, ks).to(dev)
+    with torch.no_grad():
+        for n in model.geneos:
+            model.lambdas_dict[f"lambda_{n}"].mul_(0.1)
+    return model
+
+
+def _data(dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand((2, 1, 12, 12, 16), generator=g) < 0.2).to(dev)
+    y = (torch.rand((2, 1, 12, 12, 16), generator=g) < 0.05).to(dev)
+    return x, y
+
+
+def _aliases(model):
+    flat = model._flat
+    return all(p.data_ptr() == flat.data_ptr() + 4 * i for p, i in model._leaf_slots())
+
+
+def test_effective_lambdas_kernel_is_bit_exact(hip_device):
+    rng = np.random.default_rng(0)
+    for G in (1, 3, 16, 33):
+        names = [f"{k}_{i}" for k in ("cy", "cone", "neg") for i in range(G)][:G]
+        lam = rng.uniform(-0.3, 0.4, G).astype(np.float32)
+        last = int(rng.integers(0, G))
+        order = sorted(range(G), key=lambda i: f"lambda_{names[i]}")
+        want = go.effective_lambdas(lam, last, names)
+        buf = torch.from_numpy(lam.copy()).to(hip_device)
+        got = _hip.effective_lambdas(buf, torch.tensor(order, dtype=torch.int32, device=hip_device), last)
+        assert torch.equal(got.cpu(), want)
+        assert buf[last].item() == want[last].item()          # refreshed in place (SCENE_Net.py:333)
+        keep = [i for i in range(G) if i != last]
+        assert np.array_equal(buf.cpu().numpy()[keep], lam[keep])
+
+
+def test_param_penalty_kernel_matches_oracle(hip_device):
+    rng = np.random.default_rng(1)
+    for trial in range(4):
+        n_par, n_lam = 11, 5
+        vals = rng.uniform(-1.0, 1.0, n_par + n_lam).astype(np.float32)
+        if trial == 1:
+            vals[n_par:] = np.abs(vals[n_par:]) + 0.5          # sum of free coefficients > 1: last one negative
+        last = n_par + 2
+        mask = np.array([1] * n_par + [2] * n_lam, dtype=np.int8)
+        mask[last] = 0
+        P = torch.from_numpy(vals).to(hip_device)
+        value, grad = _hip.param_penalty(P, torch.from_numpy(mask).to(hip_device), 1.5, True)
+        leaves = [torch.tensor(float(v), requires_grad=True) for v in vals]
+        cvx = {f"l{i}": leaves[n_par + i] for i in range(n_lam)}
+        cvx[f"l{2}"] = (1 - sum(v for k, v in cvx.items() if k != "l2")).detach()   # frozen last coefficient
+        params = {f"p{i}": leaves[i] for i in range(n_par)}
+        ref = lo.cvx_loss(cvx, 1.5) + lo.positive_regularizer(params, 1.5)
+        ref.backward()
+        assert abs(value.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item()))
+        want = np.array([0.0 if (l.grad is None) else l.grad.item() for l in leaves], dtype=np.float32)
+        want[last] = 0.0
+        assert np.allclose(grad.cpu().numpy(), want, atol=1e-6)
+
+
+def test_parameters_alias_one_buffer_and_survive_everything(hip_device):
+    model = _make(hip_device)
+    x, y = _data(hip_device)
+    keys_before = list(model.state_dict().keys())
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    crit = sna.GENEO_Tversky_Loss(targets=y.float(), weighting_scheme_path=None, save_weighting_scheme=False)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(model(x), y, model.get_cvx_coefficients(), model.get_geneo_params())
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    l0 = step()
+    assert _aliases(model)
+    flat_id = model._flat.data_ptr()
+    for _ in range(3):
+        step()
+    assert model._flat.data_ptr() == flat_id and _aliases(model)        # optimiser steps update the buffer in place
+    # the packed view the kernels read IS the parameters
+    r = model.geneos["cy_0"].geneo_params["radius"]
+    assert model._flat[_hip.SN_P_RADIUS].item() == r.item()
+    # inference in between re-creates the frozen coefficient (SCENE_Net.py:333); the next training forward re-aliases
+    with torch.no_grad():
+        out_inf = model(x)
+    out_trn = model(x)
+    assert _aliases(model)
+    assert torch.equal(out_inf, out_trn.detach())                       # both paths: same numbers bit for bit
+    assert abs(sum(float(p.detach()) for p in model.lambdas_dict.values()) - 1.0) < 1e-5
+    # state dict: same keys, loadable into a fresh module, values equal
+    assert list(model.state_dict().keys()) == keys_before
+    buf = io.BytesIO()
+    torch.save(model.state_dict(), buf)
+    buf.seek(0)
+    fresh = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 5, 5))
+    fresh.last_lambda = model.last_lambda
+    fresh.load_state_dict(torch.load(buf))
+    fresh = fresh.to(hip_device)
+    with torch.no_grad():
+        assert torch.equal(fresh(x), model(x))
+    # deepcopy works and is independent
+    twin = copy.deepcopy(model)
+    with torch.no_grad():
+        twin.geneos["cy_0"].geneo_params["radius"].add_(1.0)
+    assert twin.geneos["cy_0"].geneo_params["radius"].item() != model.geneos["cy_0"].geneo_params["radius"].item()
+    step()
+    assert _aliases(model)
+    # moving the module away and back re-establishes the aliasing
+    model.cpu()
+    model.to(hip_device)
+    l1 = step()
+    assert _aliases(model) and np.isfinite(l1) and l1 < l0
+
+
+def test_penalties_take_the_fused_path_and_match_the_generic_one(hip_device):
+    model = _make(hip_device, seed=5)
+    with torch.no_grad():
+        model.geneos["cy_1"].geneo_params["sigma"].fill_(-0.7)
+        model.geneos["neg_0"].geneo_params["radius"].fill_(-0.1)
+    x, y = _data(hip_device)
+    crit = sna.GENEO_Loss(targets=y.float(), weighting_scheme_path=None, save_weighting_scheme=False, convex_weight=2.0)
+    out = model(x)
+    cvx, gp = model.get_cvx_coefficients(), model.get_geneo_params()
+    assert getattr(cvx, "_sn_live").current() is not None
+    fused = crit.cvx_loss(cvx) + crit.positive_regularizer(gp)
+    both = crit._penalties(cvx, gp)
+    generic = crit.cvx_loss({k: v for k, v in cvx.items()}) + crit.positive_regularizer({k: v for k, v in gp.items()})
+    assert abs(fused.item() - generic.item()) < 1e-6 and abs(both.item() - generic.item()) < 1e-6
+    g_fused = torch.autograd.grad(both, [p for p in model.parameters() if p.requires_grad], retain_graph=True,
+                                  allow_unused=True)
+    g_gen = torch.autograd.grad(generic, [p for p in model.parameters() if p.requires_grad], allow_unused=True)
+    for a, b in zip(g_fused, g_gen):
+        assert (0.0 if a is None else a.item()) == pytest.approx(0.0 if b is None else b.item(), abs=1e-6)
+    del out
+
+
+def test_whole_training_step_replays_from_a_hip_graph(hip_device):
+    """voxel grid -> forward -> criterion -> backward -> SGD captured once, replayed; same parameters as eager."""
+    x, y = _data(hip_device, seed=4)
+
+    def build():
+        model = _make(hip_device, seed=7)
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=5e-2)
+        crit = sna.GENEO_Tversky_Loss(targets=y.float(), weighting_scheme_path=None, save_weighting_scheme=False)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(x), y, model.get_cvx_coefficients(), model.get_geneo_params())
+            loss.backward()
+            opt.step()
+            return loss
+        return model, step
+
+    eager_model, eager_step = build()
+    for _ in range(3 + 4):   # capture itself executes nothing
+        eager_step()
+    graph_model, graph_step = build()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            graph_step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graph_step()
+    for _ in range(4):
+        g.replay()
+    torch.cuda.synchronize()
+    for (n, a), (_, b) in zip(eager_model.named_parameters(), graph_model.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), n
