@@ -354,25 +354,35 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
 // ---------------------------------------------------------------- penalties over the ~50 scalars
 // geneo_loss.py:36-70 in one launch: value = w * ( sum_{mask>=1} relu(-v) + relu(-(1 - sum_{mask==2} v)) ) and its
 // gradient.  Sequential fp32 sums by one thread (slot order).
-__global__ void param_penalty_kernel(const float* __restrict__ P, const int8_t* __restrict__ mask, int N, float w,
-                                     int with_sum, float* __restrict__ value, float* __restrict__ grad) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float pen = 0.f, free_sum = 0.f;
-    for (int i = 0; i < N; ++i) {
-        const float v = P[i];
-        if (mask[i] >= 1) pen += fmaxf(-v, 0.f);
-        if (mask[i] == 2) free_sum += v;
+__global__ __launch_bounds__(256) void param_penalty_kernel(const float* __restrict__ P,
+                                                            const int8_t* __restrict__ mask, int N, float w,
+                                                            int with_sum, float* __restrict__ value,
+                                                            float* __restrict__ grad) {
+    extern __shared__ float pl[];          // [N] values, then [N] masks
+    int* ml = reinterpret_cast<int*>(pl + N);
+    __shared__ int last_neg_s;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) pl[i] = P[i], ml[i] = mask[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {                // sequential fp32 sums, slot order, out of LDS
+        float pen = 0.f, free_sum = 0.f;
+        for (int i = 0; i < N; ++i) {
+            if (ml[i] >= 1) pen += fmaxf(-pl[i], 0.f);
+            if (ml[i] == 2) free_sum += pl[i];
+        }
+        const float last = 1.f - free_sum; // the frozen coefficient, 1 - sum(others)
+        const int last_neg = with_sum && (last < 0.f);
+        if (last_neg) pen += -last;
+        last_neg_s = last_neg;
+        value[0] = w * pen;
     }
-    const float last = 1.f - free_sum;             // the frozen coefficient, 1 - sum(others)
-    const bool last_neg = with_sum && (last < 0.f);
-    if (last_neg) pen += -last;
-    for (int i = 0; i < N; ++i) {
+    __syncthreads();
+    const bool last_neg = last_neg_s != 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
         float g = 0.f;
-        if (mask[i] >= 1 && P[i] < 0.f) g -= 1.f;  // d relu(-v)/dv
-        if (mask[i] == 2 && last_neg) g += 1.f;    // d relu(-(1 - sum))/dv
+        if (ml[i] >= 1 && pl[i] < 0.f) g -= 1.f;  // d relu(-v)/dv
+        if (ml[i] == 2 && last_neg) g += 1.f;     // d relu(-(1 - sum))/dv
         grad[i] = w * g;
     }
-    value[0] = w * pen;
 }
 
 int check_common(const char* fn, const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
@@ -443,8 +453,9 @@ extern "C" int sn_param_penalty(const float* P, const int8_t* mask, int N, float
                                 float* grad, sn_stream_t stream) {
     if (!P || !mask || !value || !grad) return sn::fail(SN_ERR_INVALID_ARG, "sn_param_penalty: null pointer");
     if (N <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_param_penalty: N must be positive");
-    hipLaunchKernelGGL(param_penalty_kernel, dim3(1), dim3(64), 0, sn::as_stream(stream), P, mask, N, weight, with_sum,
-                       value, grad);
+    if (N > 8192) return sn::fail(SN_ERR_UNSUPPORTED, "sn_param_penalty: N <= 8192");
+    hipLaunchKernelGGL(param_penalty_kernel, dim3(1), dim3(256), (size_t)N * 8, sn::as_stream(stream), P, mask, N,
+                       weight, with_sum, value, grad);
     return sn::check_launch("sn_param_penalty");
 }
 
