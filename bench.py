@@ -16,6 +16,7 @@ HIP events on the launch stream; `cpu_baseline` is the oracle (CPU restatement o
 place this file touches oracle/) timed on the host cores on a bounded sample.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -157,6 +158,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # host hygiene: a full python GC pass over torch's ~10^6 objects costs tens of ms and would land at a random
+    # point of the timed loop; park everything allocated so far in the permanent generation
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -202,8 +207,9 @@ def main():
     # out by ticket.  Same results bit for bit; quoted beside the dense headline, never as `value`.
     sna._hip.set_option("conv_skip_empty_tiles", 1)
     try:
-        for _ in range(2):
-            step(False)
+        out_skip = None
+        for _ in range(3):   # also grows torch's allocator to the two extra output blocks the loop below ping-pongs
+            out_skip = step(False)
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for _ in range(n32):

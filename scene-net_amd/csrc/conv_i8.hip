@@ -21,6 +21,7 @@
 // address below its start.  Both operands use the same slot->tap table, so only the row/column lane maps of
 // the MFMA matter (A row = l&15, B col = l&15, D row = 4*(l>>4)+r, col = l&15), not the k order inside it.
 #include "common.h"
+#include <mutex>
 #include <cstdlib>
 
 namespace {
@@ -53,7 +54,8 @@ struct Shape {
     int Gtot, g0, head;  // kernel group of a larger bank: act channel stride/offset; head bits (see conv.hip)
     int perm;       // tile order multiplier, coprime to ntiles
     int skip_empty; // opt-in: skip the MFMA steps of halo tiles without a set voxel (result is exactly 0)
-    int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier
+    int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier,
+                    // 8 = prologue only, 16 = prologue + first halo fill only
 };
 
 struct TileCoord {
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     // Tile order: static (w, w+grid, ...) or, with a ticket counter (conv_skip_empty_tiles: tiles then cost very
     // different amounts), dynamic -- one thread draws the ticket of the tile after next while the rounds run.
     int tile = blockIdx.x;
-    if (tile >= s.ntiles) return;
+    if (tile >= s.ntiles || (s.dbg & 8)) return;
     if (ticket && tid == 0) *tnext = gridDim.x + atomicAdd(ticket, 1);
     __syncthreads();  // the staged bank (aliasing the halo area) is dead from here on
     {
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         if (lane == 0) wseen[wave] = w;
     }
     __syncthreads();
+    if (s.dbg & 16) return;
 
     while (tile < s.ntiles) {
         const TileCoord c = tile_coord(s, tile);
@@ -510,6 +513,23 @@ int num_cus() {
 
 namespace sn {
 
+// one int per launch out of a device-resident ring (see the launch below)
+static int* ticket_slot() {
+    constexpr int kRing = 1024, kMaxDev = 16;
+    static std::mutex mu;
+    static int* ring[kMaxDev] = {nullptr};
+    static unsigned next[kMaxDev] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring[dev] && hipMalloc((void**)&ring[dev], kRing * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        ring[dev] = nullptr;
+        return nullptr;
+    }
+    return ring[dev] + (next[dev]++ % kRing);
+}
+
 // returns SN_OK, an error, or 1 when this shape is not served by the int8 kernel (caller falls back to fp32)
 int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
                 int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream) {
@@ -556,11 +576,13 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
         s.perm = 1;
         for (int cand_p : {97, 101, 103, 107, 109, 113, 127, 131})
             if (s.ntiles % cand_p != 0) { s.perm = cand_p; break; }  // primes: coprime unless they divide ntiles
-        // dynamic tile scheduling when tile costs are data dependent: a stream-ordered 4-byte ticket counter
+        // dynamic tile scheduling when tile costs are data dependent: a ticket counter, zeroed on the launch stream.
+        // Counters come from a per-device ring allocated once (the only state this opt-in mode keeps): 1024 launches
+        // may be in flight before a slot is reused.
         int* ticket = nullptr;
         if (s.skip_empty && s.ntiles > grid) {
-            if (hipMallocAsync((void**)&ticket, sizeof(int), stream) != hipSuccess ||
-                hipMemsetAsync(ticket, 0, sizeof(int), stream) != hipSuccess) {
+            ticket = ticket_slot();
+            if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), stream) != hipSuccess) {
                 (void)hipGetLastError();
                 ticket = nullptr;  // static order still gives the right answer
             }
@@ -579,7 +601,6 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
             if (stage) SN_LAUNCH_I8(double, 80, true); else SN_LAUNCH_I8(double, 96, false);
         }
 #undef SN_LAUNCH_I8
-        if (ticket) (void)hipFreeAsync(ticket, stream);
         return check_launch("sn_conv_bank(i8)");
     }
     return 1;
