@@ -11,8 +11,10 @@
 // floats, so the 64 addresses fall into 64 different banks).
 //
 // Workgroup job = (b, delta plane z, tile of TXR input rows): delta plane (+ kx-1 halo rows, with the relu(tanh)
-// derivative fused) staged once, then the kz input planes z+dz-pz streamed through LDS; all-zero input rows are
-// skipped (binary occupancy is sparse).  Persistent workgroups; per-workgroup partial sums are reduced in a fixed
+// derivative fused) staged once, then the kz input planes z+dz-pz streamed through LDS.  Staging issues all of a
+// thread's global loads (4 elements each) before the first LDS store, so a plane costs one memory latency, not one
+// per element.  Binary occupancy is sparse: while a plane is staged every non-zero marks the K steps whose Toeplitz
+// window contains it, and a wave only issues the MFMAs of marked steps.  Persistent workgroups; per-workgroup partial sums are reduced in a fixed
 // order by corr_reduce_kernel (bit-reproducible).
 //
 // Bound: MFMA (fp32).  Algorithmic flops 2*V*kz*kx*ky per tile; the 16x16 tiles execute 2*V*kz*16*16.
@@ -38,10 +40,25 @@ struct CorrShape {
     int YK;               // K extent: Y rounded up to 32 (zero filled)
     int DR, DS;           // delta tile: rows, row stride (floats)
     int XS;               // input tile row stride (floats)
+    int vec;              // Y % 4 == 0 and 16-byte (byte input: 4-byte) aligned pointers: 4-element loads
 };
 
 template <typename T>
 __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+
+// four consecutive elements as floats
+__device__ __forceinline__ void load_quad(const uint8_t* p, float (&v)[4]) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    v[0] = (float)(u & 255u); v[1] = (float)((u >> 8) & 255u); v[2] = (float)((u >> 16) & 255u); v[3] = (float)(u >> 24);
+}
+__device__ __forceinline__ void load_quad(const float* p, float (&v)[4]) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+__device__ __forceinline__ void load_quad(const double* p, float (&v)[4]) {
+    const double2 a = reinterpret_cast<const double2*>(p)[0], b = reinterpret_cast<const double2*>(p)[1];
+    v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b.x; v[3] = (float)b.y;
+}
 
 template <typename XT, int KZMAX>
 __global__ __launch_bounds__(kThreads) void corr_mfma_kernel(const XT* __restrict__ x, const float* __restrict__ gout,
@@ -50,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void corr_mfma_kernel(const XT* __restric
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dl = lds;                                 // [DR][DS]   delta rows q0 .. q0+DR-1
     float* xl = dl + s.DR * s.DS;                    // [TXR][XS]  input rows x0 .. x0+TXR-1, columns y - py
-    int* flags = reinterpret_cast<int*>(xl + s.TXR * s.XS + 16);  // [2][TXR] row has a non-zero
+    unsigned* flags = reinterpret_cast<unsigned*>(xl + s.TXR * s.XS + 16);  // [2][TXR] K steps (of 4 y) to run
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 15, lk = lane >> 4;
     const size_t plane = (size_t)s.X * s.Y;
@@ -59,7 +76,19 @@ __global__ __launch_bounds__(kThreads) void corr_mfma_kernel(const XT* __restric
 #pragma unroll
     for (int i = 0; i < KZMAX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int i = tid; i < 2 * s.TXR; i += kThreads) flags[i] = 0;
+    for (int i = tid; i < 2 * s.TXR; i += kThreads) flags[i] = 0u;
+    const int nsteps = s.YK >> 2;   // <= 32: tracked one by one, else every step of a non-empty row runs
+    const int Y4 = s.Y >> 2;
+    if (s.vec)                      // the vector staging only writes columns that hold data: zero the padding once
+        for (int i = tid; i < s.DR * s.DS + s.TXR * s.XS; i += kThreads) lds[i] = 0.f;
+    // K steps whose window [4 ks, 4 ks + ky + 2] (LDS columns) contains column c
+    auto steps_of = [&](int c) -> unsigned {
+        if (nsteps > 32) return 0xffffffffu;
+        int lo_s = (c - s.ky - 2 + 3) >> 2, hi_s = c >> 2;
+        lo_s = lo_s < 0 ? 0 : lo_s;
+        hi_s = hi_s > nsteps - 1 ? nsteps - 1 : hi_s;
+        return (hi_s >= lo_s) ? ((0xffffffffu >> (31 - (hi_s - lo_s))) << lo_s) : 0u;
+    };
     const int ncol = lm < s.kx ? lm : s.kx - 1;      // columns dx >= kx are discarded; keep their reads in range
     int parity = 0;
 
@@ -73,51 +102,126 @@ __global__ __launch_bounds__(kThreads) void corr_mfma_kernel(const XT* __restric
         __syncthreads();  // previous job's readers of dl / xl are done
         // ---- delta tile (with d relu(tanh(s))/ds when the forward output is given)
         const size_t dbase = ((size_t)b * s.Z + z) * plane;
-        for (int i = tid; i < s.DR * s.DS; i += kThreads) {
-            const int c = i % s.DS, rr = i / s.DS, q = q0 + rr;
-            float d = 0.f;
-            if (c < s.Y && q >= 0 && q < s.X) {
-                const size_t idx = dbase + (size_t)q * s.Y + c;
-                d = gout[idx];
-                if (out) {
-                    const float o = out[idx];
-                    d = (o > 0.f) ? d * (1.f - o * o) : 0.f;
+        if (s.vec) {
+            const int nunits = s.DR * Y4;
+            for (int base = 0; base < nunits; base += 3 * kThreads) {
+                float g[3][4], o[3][4];
+                int at[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {   // all loads first
+                    const int unit = base + u * kThreads + tid;
+                    const int rr = unit / Y4, c4 = unit - rr * Y4, q = q0 + rr;
+                    at[u] = (unit < nunits) ? rr * s.DS + 4 * c4 : -1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[u][j] = 0.f, o[u][j] = 1.f;
+                    if (unit < nunits && q >= 0 && q < s.X) {
+                        const size_t idx = dbase + (size_t)q * s.Y + 4 * c4;
+                        load_quad(gout + idx, g[u]);
+                        if (out) load_quad(out + idx, o[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (at[u] < 0) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float d = g[u][j];
+                        if (out) d = (o[u][j] > 0.f) ? d * (1.f - o[u][j] * o[u][j]) : 0.f;
+                        dl[at[u] + j] = d;
+                    }
                 }
             }
-            dl[i] = d;
+        } else {
+            for (int i = tid; i < s.DR * s.DS; i += kThreads) {
+                const int c = i % s.DS, rr = i / s.DS, q = q0 + rr;
+                float d = 0.f;
+                if (c < s.Y && q >= 0 && q < s.X) {
+                    const size_t idx = dbase + (size_t)q * s.Y + c;
+                    d = gout[idx];
+                    if (out) {
+                        const float o = out[idx];
+                        d = (o > 0.f) ? d * (1.f - o * o) : 0.f;
+                    }
+                }
+                dl[i] = d;
+            }
         }
 #pragma unroll
         for (int dz = 0; dz < KZMAX; ++dz) {
             const int zp = z + dz - s.pz;
             if (dz >= s.kz || zp < 0 || zp >= s.Z) continue;  // block-uniform
-            int* fl = flags + parity * s.TXR;
-            int* fl_next = flags + (parity ^ 1) * s.TXR;
-            // ---- input plane rows -> LDS (zero halo in y), row flags
+            unsigned* fl = flags + parity * s.TXR;
+            unsigned* fl_next = flags + (parity ^ 1) * s.TXR;
+            // ---- input plane rows -> LDS (zero halo in y), K-step marks per row
             const size_t xbase = ((size_t)b * s.Z + zp) * plane;
-            for (int i = tid; i < s.TXR * s.XS; i += kThreads) {
-                const int c = i % s.XS, rr = i / s.XS, r = x0 + rr, y = c - s.py;
-                float v = 0.f;
-                if (r < s.X && y >= 0 && y < s.Y) v = to_f32(x[xbase + (size_t)r * s.Y + y]);
-                xl[i] = v;
-                if (v != 0.f) fl[rr] = 1;
+            if (s.vec) {
+                const int nunits = s.TXR * Y4;
+                for (int base = 0; base < nunits; base += 2 * kThreads) {
+                    float v[2][4];
+                    int at[2], row[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {   // all loads first
+                        const int unit = base + u * kThreads + tid;
+                        const int rr = unit / Y4, c4 = unit - rr * Y4, r = x0 + rr;
+                        at[u] = (unit < nunits) ? rr * s.XS + s.py + 4 * c4 : -1;
+                        row[u] = rr;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[u][j] = 0.f;
+                        if (unit < nunits && r < s.X) load_quad(x + xbase + (size_t)r * s.Y + 4 * c4, v[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (at[u] < 0) continue;
+                        unsigned bits = 0u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            xl[at[u] + j] = v[u][j];
+                            if (v[u][j] != 0.f) bits |= steps_of(at[u] - row[u] * s.XS + j);
+                        }
+                        if (bits) atomicOr(&fl[row[u]], bits);
+                    }
+                }
+            } else {
+                for (int i = tid; i < s.TXR * s.XS; i += kThreads) {
+                    const int c = i % s.XS, rr = i / s.XS, r = x0 + rr, y = c - s.py;
+                    float v = 0.f;
+                    if (r < s.X && y >= 0 && y < s.Y) v = to_f32(x[xbase + (size_t)r * s.Y + y]);
+                    xl[i] = v;
+                    if (v != 0.f) atomicOr(&fl[rr], steps_of(c));
+                }
             }
-            for (int i = tid; i < s.TXR; i += kThreads) fl_next[i] = 0;
+            for (int i = tid; i < s.TXR; i += kThreads) fl_next[i] = 0u;
             __syncthreads();
             // ---- rows of this wave
             for (int rr = wave; rr < s.TXR; rr += kWaves) {
-                if (!fl[rr]) continue;  // wave-uniform
+                unsigned m = __builtin_amdgcn_readfirstlane(fl[rr]);  // wave-uniform
+                if (!m) continue;
                 const float* ap = xl + rr * s.XS + lk + lm;
                 const float* bp = dl + (rr + s.kx - 1 - ncol) * s.DS + lk;
-                for (int k0 = 0; k0 < s.YK; k0 += 32) {
-                    float a[8], bb[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        a[u] = ap[k0 + 4 * u];
-                        bb[u] = bp[k0 + 4 * u];
+                if (nsteps <= 32) {
+                    while (m) {  // two marked steps per trip: the loads of both are in flight before the MFMAs
+                        const int k0 = __builtin_ctz(m) << 2;
+                        m &= m - 1;
+                        const int k1 = m ? (__builtin_ctz(m) << 2) : -1;
+                        if (m) m &= m - 1;
+                        const float a0 = ap[k0], b0 = bp[k0];
+                        float a1 = 0.f, b1 = 0.f;
+                        if (k1 >= 0) a1 = ap[k1], b1 = bp[k1];
+                        acc[dz] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[dz], 0, 0, 0);
+                        if (k1 >= 0) acc[dz] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[dz], 0, 0, 0);
                     }
+                } else {
+                    for (int k0 = 0; k0 < s.YK; k0 += 32) {
+                        float a[8], bb[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        acc[dz] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bb[u], acc[dz], 0, 0, 0);
+                        for (int u = 0; u < 8; ++u) {
+                            a[u] = ap[k0 + 4 * u];
+                            bb[u] = bp[k0 + 4 * u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            acc[dz] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bb[u], acc[dz], 0, 0, 0);
+                    }
                 }
             }
             __syncthreads();  // xl is rewritten by the next plane
@@ -211,6 +315,9 @@ int sn::corr_mfma_launch(const void* x, int x_dtype, const float* gout, const fl
     int grid;
     if (!plan(B, Z, X, Y, kz, kx, ky, &s, &lds, &grid))
         return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr: shape outside the MFMA correlation kernel");
+    const size_t xa = (x_dtype == SN_U8 || x_dtype == SN_OCC8) ? 4 : 16;
+    s.vec = (Y % 4 == 0) && ((uintptr_t)x % xa == 0) && ((uintptr_t)gout % 16 == 0) &&
+            (!out || (uintptr_t)out % 16 == 0);
 #define SN_CORR_LAUNCH(XT, KZMAX)                                                                                 \
     do {                                                                                                          \
         auto kern = corr_mfma_kernel<XT, KZMAX>;                                                                  \
