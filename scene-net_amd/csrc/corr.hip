@@ -61,7 +61,7 @@ __device__ __forceinline__ void load_quad(const double* p, float (&v)[4]) {
 }
 
 template <typename XT, int KZMAX>
-__global__ __launch_bounds__(kThreads) void corr_mfma_kernel(const XT* __restrict__ x, const float* __restrict__ gout,
+__global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel(const XT* __restrict__ x, const float* __restrict__ gout,
                                                              const float* __restrict__ out, CorrShape s,
                                                              float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -203,14 +203,15 @@ struct LossCfg {
     double mse_weight, tv_alpha, tv_beta, gamma, tv_smooth, dice_smooth;
 };
 
-__global__ __launch_bounds__(kThreads) void loss_combine_kernel(const double* __restrict__ parts, int B, int nparts,
+constexpr int kCombineThreads = 1024;
+__global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const double* __restrict__ parts, int B, int nparts,
                                                                 long n_per, int H, const float* __restrict__ bin_w,
                                                                 LossCfg cfg, double* __restrict__ stats,
                                                                 double* __restrict__ loss, double* __restrict__ coef) {
     __shared__ double tot[2 * kMaxBins + 5];
-    __shared__ double dice_part[kThreads];
+    __shared__ double dice_part[kCombineThreads];
     const int nstat = 2 * H + 5;
-    for (int i = threadIdx.x; i < B * nstat; i += kThreads) {
+    for (int i = threadIdx.x; i < B * nstat; i += kCombineThreads) {
         const int b = i / nstat, j = i % nstat;
         const double* src = parts + (size_t)b * nparts * nstat + j;
         double s = 0;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void loss_combine_kernel(const double* __
     }
     // dice, per sample (dice_loss.py:38-41), mean over the batch; gradient coefficients per sample
     double dsum = 0;
-    for (int b = threadIdx.x; b < B; b += kThreads) {
+    for (int b = threadIdx.x; b < B; b += kCombineThreads) {
         double A = 0, C = 0;
         if (cfg.terms & SN_LOSS_DICE) {
             const double* s = stats + (size_t)b * nstat + 2 * H;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void loss_combine_kernel(const double* __
             tB = dF * (-N * a) / (D * D);
         }
         if (cfg.terms & SN_LOSS_DICE) {
-            for (int i = 0; i < kThreads; ++i) dice += dice_part[i];
+            for (int i = 0; i < kCombineThreads; ++i) dice += dice_part[i];
             dice /= B;
         }
         for (int b = 0; b < B; ++b) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
 
 // ---------------------------------------------------------------- penalties over the ~50 scalars
 // geneo_loss.py:36-70 in one launch: value = w * ( sum_{mask>=1} relu(-v) + relu(-(1 - sum_{mask==2} v)) ) and its
-// gradient.  Sequential fp32 sums by one thread (slot order).
+// gradient.  fp32 sums in a fixed order (strided partials, then a tree).
 __global__ __launch_bounds__(256) void param_penalty_kernel(const float* __restrict__ P,
                                                             const int8_t* __restrict__ mask, int N, float w,
                                                             int with_sum, float* __restrict__ value,
@@ -363,17 +364,30 @@ __global__ __launch_bounds__(256) void param_penalty_kernel(const float* __restr
     __shared__ int last_neg_s;
     for (int i = threadIdx.x; i < N; i += blockDim.x) pl[i] = P[i], ml[i] = mask[i];
     __syncthreads();
-    if (threadIdx.x == 0) {                // sequential fp32 sums, slot order, out of LDS
+    // per-thread strided partial sums, then thread 0 adds the 256 partials in order (deterministic)
+    __shared__ float part_pen[256], part_sum[256];
+    {
         float pen = 0.f, free_sum = 0.f;
-        for (int i = 0; i < N; ++i) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
             if (ml[i] >= 1) pen += fmaxf(-pl[i], 0.f);
             if (ml[i] == 2) free_sum += pl[i];
         }
-        const float last = 1.f - free_sum; // the frozen coefficient, 1 - sum(others)
-        const int last_neg = with_sum && (last < 0.f);
-        if (last_neg) pen += -last;
-        last_neg_s = last_neg;
-        value[0] = w * pen;
+        part_pen[threadIdx.x] = pen;
+        part_sum[threadIdx.x] = free_sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                // 64 lanes x 4 partials, xor-tree: fixed order
+        float pen = 0.f, free_sum = 0.f;
+        for (int k = 0; k < 4; ++k) pen += part_pen[threadIdx.x * 4 + k], free_sum += part_sum[threadIdx.x * 4 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pen += __shfl_xor(pen, o, 64), free_sum += __shfl_xor(free_sum, o, 64);
+        if (threadIdx.x == 0) {
+            const float last = 1.f - free_sum; // the frozen coefficient, 1 - sum(others)
+            const int last_neg = with_sum && (last < 0.f);
+            if (last_neg) pen += -last;
+            last_neg_s = last_neg;
+            value[0] = w * pen;
+        }
     }
     __syncthreads();
     const bool last_neg = last_neg_s != 0;
@@ -444,7 +458,7 @@ extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt,
 #undef SN_STATS
     if (int rc = sn::check_launch("sn_loss_forward(stats)")) return rc;
     LossCfg cfg{terms, mse_weight, tversky_alpha, tversky_beta, focal_gamma, tversky_smooth, dice_smooth};
-    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kThreads), 0, s, parts_ws, B, nparts, (long)n_per, H, bin_w,
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kCombineThreads), 0, s, parts_ws, B, nparts, (long)n_per, H, bin_w,
                        cfg, stats, loss, coef);
     return sn::check_launch("sn_loss_forward(combine)");
 }
