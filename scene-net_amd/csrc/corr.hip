@@ -93,10 +93,13 @@ __global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel
     int parity = 0;
 
     for (int job = blockIdx.x; job < s.njobs; job += gridDim.x) {
+        // z-major job order: the planes that hold most of the set voxels (ground returns) are a few z; with b fastest
+        // a workgroup's jobs (job, job + grid, ...) land on different z instead of the same heavy one
+        // ([measured] C2, LiDAR-shaped occupancy: 204 -> 103 us)
         int j = job;
         const int xt = j % s.nxt; j /= s.nxt;
-        const int z = j % s.Z;
-        const int b = j / s.Z;
+        const int b = j % s.B;
+        const int z = j / s.B;
         const int x0 = xt * s.TXR;
         const int q0 = x0 - (s.kx - 1 - s.px);
         __syncthreads();  // previous job's readers of dl / xl are done
