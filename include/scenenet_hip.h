@@ -233,17 +233,19 @@ int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, 
  * (bit-reproducible).  The weights' mean (w_mse.py:144) is sum_k cnt_k w_k / n.
  * ------------------------------------------------------------------------- */
 #define SN_LOSS_MAX_BINS 16
-#define SN_LOSS_NSTAT(H) (2 * (H) + 5)            /* cnt[H], sq_err[H], sum_pt, sum_p, sum_t, sum_pp, sum_tt */
+#define SN_LOSS_NSTAT(H) (3 * (H) + 5)   /* cnt[H], sq_err[H], sum_pt, sum_p, sum_t, sum_pp, sum_tt, bce[H] */
 #define SN_LOSS_PARTS(n_per) ((n_per) <= 8192 ? 1 : ((n_per) >= 8192 * 256 ? 256 : (int)(((n_per) + 8191) / 8192)))
 #define SN_LOSS_WS_DOUBLES(B, n_per, H) ((int64_t)(B) * SN_LOSS_PARTS(n_per) * SN_LOSS_NSTAT(H))
-#define SN_LOSS_NCOEF(B) (SN_LOSS_MAX_BINS + 3 * (B))
-typedef enum { SN_LOSS_WMSE = 1, SN_LOSS_FOCAL_TVERSKY = 2, SN_LOSS_DICE = 4 } sn_loss_term;
+#define SN_LOSS_NCOEF(B) (2 * SN_LOSS_MAX_BINS + 3 * (B))
+typedef enum { SN_LOSS_WMSE = 1, SN_LOSS_FOCAL_TVERSKY = 2, SN_LOSS_DICE = 4, SN_LOSS_WBCE = 8 } sn_loss_term;
 
 /* Forward.  pred [B, n_per] (SN_F32 | SN_F64), gt [B, n_per] (SN_F32 | SN_F64 | SN_U8 | SN_OCC8),
  * ranges [H] f32 (left bin edges, w_mse.py:100), bin_w [H] f32 = max(1 - alpha*dens_k, eps) per bin BEFORE the
  * division by the mean (w_mse.py:128-142; ~10 numbers the host derives from the frequency table once).
- * terms = OR of sn_loss_term.  Outputs: stats [B, SN_LOSS_NSTAT(H)] f64; loss [4] f64 = {sum of the requested terms,
- * weighted MSE, focal Tversky, dice}; coef [SN_LOSS_NCOEF(B)] f64 for sn_loss_backward.
+ * terms = OR of sn_loss_term (SN_LOSS_WBCE = mean(weights * BCELoss(pred, gt)) of BinaryDiceLoss_BCE,
+ * core/criterions/dice_loss.py:71-80, with torch's clamps: log >= -100, gradient denominator >= 1e-12).
+ * Outputs: stats [B, SN_LOSS_NSTAT(H)] f64; loss [5] f64 = {sum of the requested terms, weighted MSE, focal Tversky,
+ * dice, weighted BCE}; coef [SN_LOSS_NCOEF(B)] f64 for sn_loss_backward.
  * parts_ws: scratch [SN_LOSS_WS_DOUBLES(B, n_per, H)] f64. */
 int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
                     const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
@@ -259,7 +261,8 @@ int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dty
 int sn_param_penalty(const float* P, const int8_t* mask, int N, float weight, int with_sum, float* value, float* grad,
                      sn_stream_t stream);
 
-/* Backward: grad_pred[b,i] = up * (coef[bin(gt)] (p - t) + A_b t + B_b + C_b p), in pred's dtype.
+/* Backward: grad_pred[b,i] = up * (c[bin(gt)] (p - t) + e[bin(gt)] (p - t) / max((1 - p) p, 1e-12) + A_b t + B_b + C_b p),
+ * in pred's dtype (c, e, A, B, C from coef).
  * upstream: device scalar f64 (dL/dloss), NULL = 1. */
 int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
                      const float* ranges, int H, const double* coef, const double* upstream, void* grad_pred,

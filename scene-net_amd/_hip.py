@@ -48,7 +48,7 @@ SYMBOLS = {
     "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
     "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
 }
-SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE = 1, 2, 4
+SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE, SN_LOSS_WBCE = 1, 2, 4, 8
 SN_LOSS_MAX_BINS = 16
 SN_OCC_PARTS = 16
 SN_BBOX_PARTS = 32
@@ -329,18 +329,18 @@ def loss_parts(n_per: int) -> int:
 def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int,
                  mse_weight: float = 1.0, tversky_alpha: float = 0.5, tversky_beta: float = 1.0,
                  focal_gamma: float = 1.0, tversky_smooth: float = 1.0, dice_smooth: float = 1.0):
-    """sn_loss_forward on pred/gt [B, ...] (same shape).  Returns (loss [4] f64 = {total, wmse, focal tversky, dice},
-    stats [B, 2H+5] f64, coef f64 for loss_backward)."""
+    """sn_loss_forward on pred/gt [B, ...] (same shape).  Returns (loss [5] f64 = {total, wmse, focal tversky, dice,
+    weighted bce}, stats [B, 3H+5] f64, coef f64 for loss_backward)."""
     if pred.shape != gt.shape:
         raise HipLibraryError(f"pred {tuple(pred.shape)} and gt {tuple(gt.shape)} must have the same shape")
     B = int(pred.shape[0])
     n_per = pred.numel() // max(B, 1)
     H = int(ranges.numel())
     dev = pred.device
-    ws = torch.empty((B * loss_parts(n_per) * (2 * H + 5),), dtype=torch.float64, device=dev)
-    stats = torch.empty((B, 2 * H + 5), dtype=torch.float64, device=dev)
-    loss = torch.empty((4,), dtype=torch.float64, device=dev)
-    coef = torch.empty((SN_LOSS_MAX_BINS + 3 * B,), dtype=torch.float64, device=dev)
+    ws = torch.empty((B * loss_parts(n_per) * (3 * H + 5),), dtype=torch.float64, device=dev)
+    stats = torch.empty((B, 3 * H + 5), dtype=torch.float64, device=dev)
+    loss = torch.empty((5,), dtype=torch.float64, device=dev)
+    coef = torch.empty((2 * SN_LOSS_MAX_BINS + 3 * B,), dtype=torch.float64, device=dev)
     rc = load().sn_loss_forward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
                                 n_per, _ptr(ranges, torch.float32, "ranges"), _ptr(bin_w, torch.float32, "bin_w"), H,
                                 int(terms), float(mse_weight), float(tversky_alpha), float(tversky_beta),

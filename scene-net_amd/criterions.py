@@ -267,6 +267,25 @@ class BinaryDiceLoss(torch.nn.Module):
         return loss if self.reduction == "mean" else loss * predict.shape[0]
 
 
+class BinaryDiceLoss_BCE(WeightedMSE):
+    """dice_loss.py:55-95: weights * BCELoss + BinaryDiceLoss, one pass over (pred, gt).  reduction 'mean' or 'sum'."""
+
+    def __init__(self, targets=None, weighting_scheme_path=HIST_PATH, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
+                 reduction="mean", **kwargs) -> None:
+        super().__init__(targets, weighting_scheme_path, weight_alpha, weight_epsilon, mse_weight, **kwargs)
+        self.dice = BinaryDiceLoss(reduction=reduction)
+        self.reduction = reduction
+
+    def forward(self, predict, target):
+        ranges, bin_w = self._device_tables(predict.device)
+        if self.reduction == "mean":   # mean(w * bce) + mean_b(dice_b)
+            return _dense_loss(predict, target, ranges, bin_w, _hip.SN_LOSS_WBCE | _hip.SN_LOSS_DICE,
+                               dice_smooth=self.dice.smooth)
+        # 'sum': sum(w * bce) + sum_b(dice_b) = n * mean(w * bce) + B * mean_b(dice_b)
+        bce = _dense_loss(predict, target, ranges, bin_w, _hip.SN_LOSS_WBCE)
+        return bce * predict.numel() + self.dice(predict, target)
+
+
 class GENEO_Loss(WeightedMSE):
     """geneo_loss.py:24-90: weighted MSE + penalties on non-positive convex coefficients / GENEO parameters."""
 
@@ -334,6 +353,25 @@ class GENEO_Dice_Loss(GENEO_Loss):
 
     def _terms(self):
         return _hip.SN_LOSS_WMSE | _hip.SN_LOSS_DICE, dict(dice_smooth=self.dice.smooth)
+
+
+class GENEO_Dice_BCE(GENEO_Loss):
+    """geneo_loss.py:110-128: mse_weight * (weights * BCE + dice) + penalties.  (The reference's constructor passes
+    its arguments to BinaryDiceLoss_BCE in the wrong positions and raises a TypeError; this is the evident intent.)"""
+
+    def __init__(self, targets=None, weighting_scheme_path=None, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
+                 convex_weight=1, reduction="mean", **kwargs) -> None:
+        super().__init__(targets, weighting_scheme_path, weight_alpha, weight_epsilon, mse_weight, convex_weight,
+                         **kwargs)
+        if reduction != "mean":
+            raise NotImplementedError("GENEO_Dice_BCE on the HIP path: reduction 'mean'")
+        self.dice = BinaryDiceLoss()
+
+    def forward(self, y_pred, y_gt, cvx_coeffs, geneo_params):
+        ranges, bin_w = self._device_tables(y_pred.device)
+        dense = _dense_loss(y_pred, y_gt, ranges, bin_w, _hip.SN_LOSS_WBCE | _hip.SN_LOSS_DICE,
+                            dice_smooth=self.dice.smooth)
+        return self.mse_weight * dense + self._penalties(cvx_coeffs, geneo_params)
 
 
 class GENEO_Tversky_Loss(GENEO_Loss):

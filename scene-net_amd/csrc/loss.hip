@@ -53,6 +53,13 @@ __device__ __forceinline__ void store4(T* p, const Vec4<T>& r) {
     }
 }
 
+// max(log(v), -100) as torch's binary_cross_entropy clamps it, in pred's dtype
+template <typename T>
+__device__ __forceinline__ T bce_log(T v) {
+    if constexpr (sizeof(T) == 8) return fmax(log(v), -100.0);
+    else return fmaxf(logf(v), -100.0f);
+}
+
 // w_mse.py:122 -- argmin_k |y - ranges[k]|, first minimum; arithmetic in gt's dtype promoted with the fp32 ranges
 // (f64 gt: fp64; f32 gt: fp32; byte gt, our extension: fp32).
 template <typename GT>
@@ -101,10 +108,13 @@ __device__ __forceinline__ int bin_lookup(const BinOf<GT>& bin, const int* lut, 
 template <typename PT, typename GT, bool kBinary>
 __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restrict__ pred, const GT* __restrict__ gt,
                                                               long n_per, long span, const float* __restrict__ ranges,
-                                                              int H, double* __restrict__ parts) {
-    __shared__ double red[kThreads / 64][2 * kMaxBins + 5];
+                                                              int H, int terms, double* __restrict__ parts) {
+    __shared__ double red[kThreads / 64][3 * kMaxBins + 5];
     __shared__ double sq_l[kBinary ? 1 : kMaxBins * kThreads];
     __shared__ int cnt_l[kBinary ? 1 : kMaxBins * kThreads];
+    using BT = PT;  // per-thread per-bin BCE partials in pred's precision (a few hundred terms each)
+    __shared__ BT bce_l[kBinary ? 1 : kMaxBins * kThreads];
+    const bool want_bce = (terms & SN_LOSS_WBCE) != 0;
     __shared__ int lut[256];
     const int part = blockIdx.x, b = blockIdx.y, nparts = gridDim.x, tid = threadIdx.x;
     const long lo = (long)part * span, hi = (lo + span < n_per) ? lo + span : n_per;
@@ -113,12 +123,12 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
     BinOf<GT> bin;
     bin.init(ranges, H);
     const int lane = tid & 63, wave = tid >> 6;
-    const int nstat = 2 * H + 5;
+    const int nstat = 3 * H + 5;
     double s_pt = 0, s_p = 0, s_t = 0, s_pp = 0, s_tt = 0;
     const bool vec = (n_per % 4 == 0);  // the sample base is then 4-element aligned (host checks the pointers)
 
     if constexpr (kBinary) {
-        double sq_all = 0, sq1 = 0;
+        double sq_all = 0, sq1 = 0, bce_all = 0, bce1 = 0;
         int n_all = 0, n1 = 0;
         auto take = [&](PT pv, GT tv) {
             const double pd = (double)pv;
@@ -131,6 +141,11 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
             s_pt += one ? pd : 0.0;
             s_p += pd;
             s_pp += pd * pd;
+            if (want_bce) {  // torch BCELoss: -(t max(log p, -100) + (1 - t) max(log(1 - p), -100)), in pred's dtype
+                const PT l = bce_log<PT>(one ? pv : (PT)1 - pv);
+                bce_all -= (double)l;
+                bce1 -= one ? (double)l : 0.0;
+            }
         };
         if (vec) {
             for (long i = lo + 4 * (long)tid; i + 3 < hi; i += 4 * kThreads) {
@@ -146,16 +161,18 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
         const double c1 = wave_sum((double)n1), c0 = wave_sum((double)(n_all - n1));
         const double q1 = wave_sum(sq1), q0 = wave_sum(sq_all - sq1);
         const double a = wave_sum(s_pt), c = wave_sum(s_p), e = wave_sum(s_pp);
+        const double g1 = wave_sum(bce1), g0 = wave_sum(bce_all - bce1);
         if (lane == 0) {
-            for (int j = 0; j < 2 * H; ++j) red[wave][j] = 0.0;
+            for (int j = 0; j < nstat; ++j) red[wave][j] = 0.0;
             red[wave][b0] += c0; red[wave][b1] += c1;
             red[wave][H + b0] += q0; red[wave][H + b1] += q1;
+            red[wave][2 * H + 5 + b0] += g0; red[wave][2 * H + 5 + b1] += g1;
             red[wave][2 * H + 0] = a; red[wave][2 * H + 1] = c; red[wave][2 * H + 2] = c1;
             red[wave][2 * H + 3] = e; red[wave][2 * H + 4] = c1;
         }
     } else {
         if constexpr (sizeof(GT) == 1) lut[tid] = bin((GT)tid);
-        for (int k = 0; k < H; ++k) sq_l[k * kThreads + tid] = 0.0, cnt_l[k * kThreads + tid] = 0;
+        for (int k = 0; k < H; ++k) sq_l[k * kThreads + tid] = 0.0, cnt_l[k * kThreads + tid] = 0, bce_l[k * kThreads + tid] = (BT)0;
         __syncthreads();
         auto take = [&](PT pv, GT tv) {
             const double pd = (double)pv, td = (double)tv;
@@ -163,6 +180,10 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
             const int k = bin_lookup(bin, lut, tv) * kThreads + tid;
             sq_l[k] += e * e;
             cnt_l[k] += 1;
+            if (want_bce) {
+                const PT tt = (PT)tv;
+                bce_l[k] -= tt * bce_log<PT>(pv) + ((PT)1 - tt) * bce_log<PT>((PT)1 - pv);
+            }
             s_pt += pd * td;
             s_p += pd;
             s_t += td;
@@ -181,7 +202,8 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
         }
         for (int j = 0; j < H; ++j) {
             const double a = wave_sum((double)cnt_l[j * kThreads + tid]), c = wave_sum(sq_l[j * kThreads + tid]);
-            if (lane == 0) red[wave][j] = a, red[wave][H + j] = c;
+            const double g = wave_sum((double)bce_l[j * kThreads + tid]);
+            if (lane == 0) red[wave][j] = a, red[wave][H + j] = c, red[wave][2 * H + 5 + j] = g;
         }
         const double a = wave_sum(s_pt), c = wave_sum(s_p), d = wave_sum(s_t), e = wave_sum(s_pp), f = wave_sum(s_tt);
         if (lane == 0) {
@@ -208,9 +230,9 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
                                                                 long n_per, int H, const float* __restrict__ bin_w,
                                                                 LossCfg cfg, double* __restrict__ stats,
                                                                 double* __restrict__ loss, double* __restrict__ coef) {
-    __shared__ double tot[2 * kMaxBins + 5];
+    __shared__ double tot[3 * kMaxBins + 5];
     __shared__ double dice_part[kCombineThreads];
-    const int nstat = 2 * H + 5;
+    const int nstat = 3 * H + 5;
     for (int i = threadIdx.x; i < B * nstat; i += kCombineThreads) {
         const int b = i / nstat, j = i % nstat;
         const double* src = parts + (size_t)b * nparts * nstat + j;
@@ -251,15 +273,15 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
             A = -1.0 / den / B;               // d(1 - num/den)/dp_i = -(t_i den - num 2 p_i)/den^2
             C = 2.0 * num / (den * den) / B;
         }
-        coef[kMaxBins + 3 * b + 0] = A;
-        coef[kMaxBins + 3 * b + 1] = 0.0;
-        coef[kMaxBins + 3 * b + 2] = C;
+        coef[2 * kMaxBins + 3 * b + 0] = A;
+        coef[2 * kMaxBins + 3 * b + 1] = 0.0;
+        coef[2 * kMaxBins + 3 * b + 2] = C;
     }
     dice_part[threadIdx.x] = dsum;
     __syncthreads();
     if (threadIdx.x == 0) {
         const double n = (double)B * (double)n_per;
-        double wmse = 0, focal = 0, dice = 0;
+        double wmse = 0, focal = 0, dice = 0, wbce = 0;
         double mean_w = 0;
         for (int k = 0; k < H; ++k) mean_w += tot[k] * (double)bin_w[k];
         mean_w /= n;
@@ -271,7 +293,15 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
                 c = 2.0 * cfg.mse_weight * wk / n;                 // d/dp of mean(mse_weight w (t - p)^2)
             }
             coef[k] = c;
+            double e = 0;
+            if (k < H && (cfg.terms & SN_LOSS_WBCE)) {             // mean(w * bce), dice_loss.py:77-80
+                const double wk = (double)bin_w[k] / mean_w;
+                wbce += wk * tot[2 * H + 5 + k];
+                e = wk / n;
+            }
+            coef[kMaxBins + k] = e;
         }
+        wbce = (cfg.terms & SN_LOSS_WBCE) ? wbce / n : 0.0;
         wmse = (cfg.terms & SN_LOSS_WMSE) ? cfg.mse_weight * wmse / n : 0.0;
         double tA = 0, tB = 0;
         if (cfg.terms & SN_LOSS_FOCAL_TVERSKY) {                   // tversky_loss.py:86-93
@@ -289,10 +319,11 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
             dice /= B;
         }
         for (int b = 0; b < B; ++b) {
-            coef[kMaxBins + 3 * b + 0] += tA;
-            coef[kMaxBins + 3 * b + 1] += tB;
+            coef[2 * kMaxBins + 3 * b + 0] += tA;
+            coef[2 * kMaxBins + 3 * b + 1] += tB;
         }
-        loss[0] = wmse + focal + dice;
+        loss[0] = wmse + focal + dice + wbce;
+        loss[4] = wbce;
         loss[1] = wmse;
         loss[2] = focal;
         loss[3] = dice;
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
                                                              const double* __restrict__ upstream,
                                                              PT* __restrict__ grad) {
     using C = PT;  // gradient arithmetic in pred's dtype
-    __shared__ C ck[kMaxBins];
+    __shared__ C ck[kMaxBins], ek[kMaxBins];
     __shared__ int lut[256];
     const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const long lo = (long)part * span, hi = (lo + span < n_per) ? lo + span : n_per;
@@ -317,25 +348,42 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
     BinOf<GT> bin;
     bin.init(ranges, H);
     const double up = upstream ? *upstream : 1.0;
-    const C A = (C)(coef[kMaxBins + 3 * b] * up), Bc = (C)(coef[kMaxBins + 3 * b + 1] * up),
-            Cc = (C)(coef[kMaxBins + 3 * b + 2] * up);
-    C c0 = 0, c1 = 0;
+    const C A = (C)(coef[2 * kMaxBins + 3 * b] * up), Bc = (C)(coef[2 * kMaxBins + 3 * b + 1] * up),
+            Cc = (C)(coef[2 * kMaxBins + 3 * b + 2] * up);
+    C c0 = 0, c1 = 0, e0 = 0, e1 = 0;
+    bool any_e = false;   // weighted-BCE term present (block-uniform)
+    for (int k = 0; k < kMaxBins; ++k) any_e |= coef[kMaxBins + k] != 0.0;
     if constexpr (kBinary) {
         c0 = (C)(coef[bin((GT)0)] * up);
         c1 = (C)(coef[bin((GT)1)] * up);
+        e0 = (C)(coef[kMaxBins + bin((GT)0)] * up);
+        e1 = (C)(coef[kMaxBins + bin((GT)1)] * up);
     } else {
-        if (tid < kMaxBins) ck[tid] = (C)(coef[tid] * up);
+        if (tid < kMaxBins) ck[tid] = (C)(coef[tid] * up), ek[tid] = (C)(coef[kMaxBins + tid] * up);
         if constexpr (sizeof(GT) == 1) lut[tid] = bin((GT)tid);
         __syncthreads();
     }
     auto one = [&](PT pv, GT tv) -> PT {
         const C pc = (C)pv;
+        // d bce / dp as torch computes it: (p - t) / max((1 - p) p, EPSILON), EPSILON = float(1e-12) in ATen
+        const C kBceEps = (C)1e-12f;
         if constexpr (kBinary) {
             // t in {0,1}:  c (p - t) + A t + B + C p
-            return (tv != 0) ? (PT)(c1 * (pc - (C)1) + A + Bc + Cc * pc) : (PT)(c0 * pc + Bc + Cc * pc);
+            C g = (tv != 0) ? (c1 * (pc - (C)1) + A + Bc + Cc * pc) : (c0 * pc + Bc + Cc * pc);
+            if (any_e) {
+                const C den = ((C)1 - pc) * pc;
+                g += ((tv != 0) ? e1 * (pc - (C)1) : e0 * pc) / (den > kBceEps ? den : kBceEps);
+            }
+            return (PT)g;
         } else {
-            const C c = ck[bin_lookup(bin, lut, tv)], tc = (C)tv;
-            return (PT)(c * (pc - tc) + A * tc + Bc + Cc * pc);
+            const int k = bin_lookup(bin, lut, tv);
+            const C c = ck[k], tc = (C)tv;
+            C g = c * (pc - tc) + A * tc + Bc + Cc * pc;
+            if (any_e) {
+                const C den = ((C)1 - pc) * pc;
+                g += ek[k] * (pc - tc) / (den > kBceEps ? den : kBceEps);
+            }
+            return (PT)g;
         }
     };
     if (n_per % 4 == 0) {
@@ -445,7 +493,7 @@ extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt,
     if (int rc = check_common("sn_loss_forward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
     if (!bin_w || !parts_ws || !stats || !loss || !coef)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_forward: null pointer");
-    if (terms <= 0 || (terms & ~(SN_LOSS_WMSE | SN_LOSS_FOCAL_TVERSKY | SN_LOSS_DICE)))
+    if (terms <= 0 || (terms & ~(SN_LOSS_WMSE | SN_LOSS_FOCAL_TVERSKY | SN_LOSS_DICE | SN_LOSS_WBCE)))
         return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_forward: bad terms mask %d", terms);
     if (B > 65535) return sn::fail(SN_ERR_UNSUPPORTED, "sn_loss_forward: B <= 65535");
     hipStream_t s = sn::as_stream(stream);
@@ -453,7 +501,7 @@ extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt,
     const long span = span_of(n_per, nparts);
 #define SN_STATS(PT, GT, BIN)                                                                                     \
     hipLaunchKernelGGL((loss_stats_kernel<PT, GT, BIN>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,  \
-                       (const GT*)gt, (long)n_per, span, ranges, H, parts_ws)
+                       (const GT*)gt, (long)n_per, span, ranges, H, terms, parts_ws)
     SN_LOSS_DISPATCH(SN_STATS);
 #undef SN_STATS
     if (int rc = sn::check_launch("sn_loss_forward(stats)")) return rc;

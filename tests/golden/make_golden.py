@@ -277,6 +277,7 @@ def dump_loss():
     hist_frequency_estimation.  The classes write ./hist_estimation.pickle, so they are built in a scratch cwd."""
     import tempfile
     from core.criterions.geneo_loss import GENEO_Dice_Loss, GENEO_Loss, GENEO_Tversky_Loss
+    from core.criterions.dice_loss import BinaryDiceLoss_BCE
 
     cases = {
         # name: (shape, dtype, gt kind, explicit freqs or None (estimate from gt), hyper-parameters)
@@ -322,6 +323,16 @@ def dump_loss():
                     out[f"{name}|{cls_name}|grad_cvx"] = np.array(
                         [0.0 if cvx[n].grad is None else float(cvx[n].grad) for n in names])
                     out[f"{name}|{cls_name}|grad_params"] = np.array([float(gp[n].grad) for n in gpar])
+                for red in ("mean", "sum"):   # the stand-alone weighted BCE + dice criterion ('dice_bce')
+                    hp_w = {k: v for k, v in hp.items() if k in ("weight_alpha", "weight_epsilon", "mse_weight")}
+                    crit = BinaryDiceLoss_BCE(targets=gt, weighting_scheme_path=None, reduction=red, **hp_w)
+                    if freqs is not None:
+                        crit.freqs = torch.tensor(freqs, dtype=torch.int64)
+                    pred = pred0.clone().clamp(1e-4, 1 - 1e-4).requires_grad_(True)
+                    loss = crit(pred, gt)
+                    loss.backward()
+                    out[f"{name}|dice_bce_{red}|loss"] = loss.detach().numpy()
+                    out[f"{name}|dice_bce_{red}|grad_pred"] = pred.grad.numpy()
                 out[f"{name}|pred"] = pred0.numpy()
                 out[f"{name}|gt"] = gt.numpy()
                 out[f"{name}|freqs"] = crit.freqs.numpy()

@@ -64,6 +64,40 @@ def test_reference_golden_losses_and_gradients(hip_device, name, kind):
     np.testing.assert_allclose(got, GOLD[f"{name}|{kind}|grad_params"], rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("red", ["mean", "sum"])
+@pytest.mark.parametrize("name", CASES)
+def test_dice_bce_reference_golden(hip_device, name, red):
+    """BinaryDiceLoss_BCE ('dice_bce'): weights * BCELoss + dice, against the reference's own numbers."""
+    hp = ast.literal_eval(str(GOLD[f"{name}|hp"]))
+    hp = {k: v for k, v in hp.items() if k in ("weight_alpha", "weight_epsilon", "mse_weight")}
+    gt = torch.from_numpy(GOLD[f"{name}|gt"])
+    crit = sna.BinaryDiceLoss_BCE(targets=gt, weighting_scheme_path=None, save_weighting_scheme=False, reduction=red, **hp)
+    crit.freqs = torch.from_numpy(GOLD[f"{name}|freqs"]).to(hip_device)
+    pred = torch.from_numpy(GOLD[f"{name}|pred"]).clamp(1e-4, 1 - 1e-4).to(hip_device).requires_grad_(True)
+    loss = crit(pred, gt.to(hip_device))
+    loss.backward()
+    ref, gref = float(GOLD[f"{name}|dice_bce_{red}|loss"]), GOLD[f"{name}|dice_bce_{red}|grad_pred"]
+    tol = _tol(pred.dtype)
+    assert abs(loss.item() - ref) <= tol * abs(ref), (loss.item(), ref)
+    err = np.abs(pred.grad.cpu().numpy() - gref).max()
+    assert err <= tol * np.abs(gref).max(), (err, np.abs(gref).max())
+
+
+def test_bce_clamps_like_torch(hip_device):
+    """p = 0 and p = 1 exactly: log clamped at -100, gradient denominator at 1e-12 (torch's BCELoss)."""
+    pred = torch.tensor([[0.0, 1.0, 0.0, 1.0, 0.3, 0.999999]], dtype=torch.float64)
+    gt = torch.tensor([[0.0, 1.0, 1.0, 0.0, 1.0, 0.0]], dtype=torch.float64)
+    ranges = torch.zeros(1, dtype=torch.float32, device=hip_device)
+    bin_w = torch.ones(1, dtype=torch.float32, device=hip_device)
+    loss, _, coef = _hip.loss_forward(pred.to(hip_device), gt.to(hip_device), ranges, bin_w, _hip.SN_LOSS_WBCE)
+    po = pred.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy(po, gt)
+    ref.backward()
+    assert abs(loss[0].item() - ref.item()) <= 1e-12 * ref.item()
+    g = _hip.loss_backward(pred.to(hip_device), gt.to(hip_device), ranges, coef).cpu()
+    assert torch.allclose(g, po.grad, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_weight_target_matches_reference(hip_device, name):
     crit, gt, _, _, _ = _build(name, "geneo", hip_device)
@@ -120,19 +154,20 @@ def test_full_size_properties(hip_device):
     pred = torch.rand((B, 1, 64, 64, 64), device=hip_device, dtype=torch.float64)
     ranges = torch.linspace(0, 1, 11)[:-1].to(hip_device).contiguous()
     bin_w = torch.linspace(0.1, 1.0, 10).to(hip_device).contiguous()
-    terms = _hip.SN_LOSS_WMSE | _hip.SN_LOSS_FOCAL_TVERSKY | _hip.SN_LOSS_DICE
+    terms = _hip.SN_LOSS_WMSE | _hip.SN_LOSS_FOCAL_TVERSKY | _hip.SN_LOSS_DICE | _hip.SN_LOSS_WBCE
+    pred = pred.clamp(0.05, 0.95)   # keeps the BCE term's higher derivatives tame for the difference quotient
     l1, stats, coef = _hip.loss_forward(pred, gt, ranges, bin_w, terms, focal_gamma=1.5)
     l2, stats2, coef2 = _hip.loss_forward(pred, gt, ranges, bin_w, terms, focal_gamma=1.5)
     assert torch.equal(l1, l2) and torch.equal(stats, stats2) and torch.equal(coef, coef2)
     assert stats[:, :10].sum().item() == B * n
     assert stats[:, 0].sum().item() == (~gt).sum().item() and stats[:, 9].sum().item() == gt.sum().item()
-    assert abs(l1[0].item() - (l1[1] + l1[2] + l1[3]).item()) < 1e-12
+    assert abs(l1[0].item() - (l1[1] + l1[2] + l1[3] + l1[4]).item()) < 1e-12
     g1 = _hip.loss_backward(pred, gt, ranges, coef)
     up = torch.tensor([2.5], dtype=torch.float64, device=hip_device)
     g2 = _hip.loss_backward(pred, gt, ranges, coef, up)
     assert (g2 - 2.5 * g1).abs().max().item() <= 1e-12 * g1.abs().max().item()
     d = g1 / g1.abs().max() + 0.1 * torch.randn_like(pred)
-    h = 1e-4
+    h = 1e-5
     lp = _hip.loss_forward(pred + h * d, gt, ranges, bin_w, terms, focal_gamma=1.5)[0][0].item()
     lm = _hip.loss_forward(pred - h * d, gt, ranges, bin_w, terms, focal_gamma=1.5)[0][0].item()
     fd = (lp - lm) / (2 * h)
