@@ -67,3 +67,31 @@ class ScenePipeline:
         grids = self.voxelize(batch, want_gt)
         out = self.model(grids.occ)
         return (out, grids) if want_gt else out
+
+    def capture(self, batch: PointBatch, want_gt: bool = False) -> "CapturedPipeline":
+        """The whole pass over `batch` (its device buffers, as they are refilled in place later) recorded into one
+        hipGraph: 7 launches replayed with one call and no dispatch gaps.  Inference only (runs under no_grad)."""
+        return CapturedPipeline(self, batch, want_gt)
+
+
+class CapturedPipeline:
+    """A hipGraph of ScenePipeline.__call__ over one PointBatch's buffers.  `replay()` re-runs it on whatever the
+    buffers hold now (same number of tiles and points per tile offsets as at capture) and returns the static outputs.
+    Every launch of the C ABI goes to torch's current stream and nothing on the path synchronises or allocates outside
+    torch's allocator, so the capture needs no special casing."""
+
+    def __init__(self, pipe: ScenePipeline, batch: PointBatch, want_gt: bool = False):
+        self.batch = batch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            pipe(batch, want_gt)  # warm-up off the capture stream: lazy initialisation, allocator growth
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            res = pipe(batch, want_gt)
+        self.out, self.grids = res if want_gt else (res, None)
+
+    def replay(self):
+        self.graph.replay()
+        return (self.out, self.grids) if self.grids is not None else self.out

@@ -118,3 +118,28 @@ def test_v1_module_and_wrappers(hip_device, golden_dir):
 def test_smoke_entry(hip_device):
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_captured_pipeline_replays_on_refilled_buffers(hip_device):
+    """ScenePipeline.capture: one hipGraph for the whole pass; replay on new points in the same buffers == eager."""
+    from scene_net_amd.synthetic import synthetic_tile
+    torch.manual_seed(0)
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    pipe = sna.ScenePipeline(model, (32, 32, 32), keep_labels=[15])
+    tiles, labels = zip(*[synthetic_tile(t, 20_000) for t in range(3)])
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    cap = pipe.capture(batch, want_gt=True)
+    out, grids = cap.replay()
+    with torch.no_grad():
+        ref_out, ref_grids = pipe(batch, want_gt=True)
+    assert torch.equal(out, ref_out) and torch.equal(grids.occ, ref_grids.occ) and torch.equal(grids.gt_occ, ref_grids.gt_occ)
+    # refill the same device buffers with other tiles (same sizes) and replay
+    tiles2, labels2 = zip(*[synthetic_tile(100 + t, 20_000) for t in range(3)])
+    other = sna.PointBatch.from_tiles(tiles2, labels2, device=hip_device)
+    batch.pts.copy_(other.pts)
+    batch.labels.copy_(other.labels)
+    out2, grids2 = cap.replay()
+    with torch.no_grad():
+        ref2, refg2 = pipe(other, want_gt=True)
+    assert torch.equal(out2, ref2) and torch.equal(grids2.occ, refg2.occ)
+    assert not torch.equal(ref2, ref_out)
