@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the graph-replay and skip-empty extras (profiling runs: keeps per-kernel averages clean)")
     return ap.parse_args()
 
 
@@ -203,28 +205,35 @@ def main():
     conv32_ms = e0.elapsed_time(e1) / n32
     conv32_tflops = conv_flops / (conv32_ms * 1e-3) / 1e12
 
-    # opt-in data-dependent mode (sn_set_option): tiles whose halo is empty skip their MFMA loop, tiles are handed
-    # out by ticket.  Same results bit for bit; quoted beside the dense headline, never as `value`.
-    sna._hip.set_option("conv_skip_empty_tiles", 1)
-    try:
-        out_skip = None
-        for _ in range(3):   # also grows torch's allocator to the two extra output blocks the loop below ping-pongs
-            out_skip = step(False)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for _ in range(n32):
-            out_skip = step(False)
-        torch.cuda.synchronize()
-        skip_ms = (time.perf_counter() - ts) / n32 * 1e3
-        skip_same = bool(torch.equal(out_skip, out))
-    finally:
-        sna._hip.set_option("conv_skip_empty_tiles", 0)
+    skip_info = None
+    if not args.no_extras:
+        # opt-in data-dependent mode (sn_set_option): tiles whose halo is empty skip their MFMA loop, tiles are handed
+        # out by ticket.  Same results bit for bit; quoted beside the dense headline, never as `value`.
+        sna._hip.set_option("conv_skip_empty_tiles", 1)
+        try:
+            out_skip = None
+            for _ in range(3):   # also grows torch's allocator to the two extra output blocks the loop below ping-pongs
+                out_skip = step(False)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(n32):
+                out_skip = step(False)
+            torch.cuda.synchronize()
+            skip_ms = (time.perf_counter() - ts) / n32 * 1e3
+            skip_same = bool(torch.equal(out_skip, out))
+        finally:
+            sna._hip.set_option("conv_skip_empty_tiles", 0)
+        skip_info = {"ms_per_step": skip_ms, "tiles_per_s_per_gpu": B / (skip_ms * 1e-3), "identical_output": skip_same,
+                     "note": "opt-in conv_skip_empty_tiles=1 on this rank's synthetic LiDAR-shaped batch; data dependent, "
+                             "not the headline"}
 
     # the same step captured once into a hipGraph and replayed (nothing on the path synchronises or allocates outside
     # torch's allocator, every launch goes to the current stream): removes the ~20 us of dispatch gaps per step.
     # Reported beside the eager headline, never as `value`.
     graph_info = None
     try:
+        if args.no_extras:
+            raise RuntimeError("skipped (--no-extras)")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -284,10 +293,7 @@ def main():
                            "unit": "GB/s", "frac": vox_gbs / PEAK_HBM_GBS, "traffic": traffic.get("voxel_stage"),
                            "stage_ms": vox_ms, "bytes_per_stage": vox_bytes},
         "graph_replay": graph_info,
-        "skip_empty_tiles": {"ms_per_step": skip_ms, "tiles_per_s_per_gpu": B / (skip_ms * 1e-3),
-                             "identical_output": skip_same,
-                             "note": "opt-in conv_skip_empty_tiles=1 on this rank's synthetic LiDAR-shaped batch; "
-                                     "data dependent, not the headline"},
+        "skip_empty_tiles": skip_info,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
