@@ -32,6 +32,7 @@ SYMBOLS = {
     "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_effective_lambdas": (c_int, [_P, _P, _I, _I, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_conv_fused": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
     "sn_voxel_desc": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sn_voxel_desc_from_bounds": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
@@ -149,6 +150,29 @@ def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tenso
                              _ptr(act, None, "act"), _ptr(out, None, "out"), _DT_OUT[out_dtype], _stream())
     _check(rc, "sn_conv_bank")
     return act, out
+
+
+def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
+    """Shapes sn_conv_fused serves: binary occupancy, Y % 4 == 0, a 16-y strip's window within 32 bytes, tables in LDS."""
+    kz, kx, ky = (int(k) for k in kernel_size)
+    py = (ky - 1) // 2
+    pya = (py + 3) & ~3
+    lds = ((kz * kx + 1) // 2) * (3 * 1024 + 16) + 80 + max((8 + kz - 1) * (16 + kx - 1) * 80, kz * kx * ky * 4)
+    return (x.dtype == torch.bool and x.dim() == 5 and x.shape[-1] % 4 == 0 and pya - py + 15 + ky - 1 < 32
+            and lds <= 160 * 1024)
+
+
+def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
+               out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """relu(tanh(conv3d(x, sum_g lambda_g K_g))) [B,1,Z,X,Y] (sn_conv_fused): the forward output through linearity."""
+    B, _, Z, X, Y = x.shape
+    G, kz, kx, ky = bank.shape
+    out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device)
+    rc = load().sn_conv_fused(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                              _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky, _ptr(out),
+                              _DT_OUT[out_dtype], _stream())
+    _check(rc, "sn_conv_fused")
+    return out
 
 
 def desc_len(nx: int, ny: int, nz: int) -> int:

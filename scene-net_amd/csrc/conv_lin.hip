@@ -1,0 +1,274 @@
+// K3L -- SceneNet.forward through LINEARITY, for binary occupancy on the int8 matrix cores.
+//
+// relu(tanh(sum_g lambda_g conv3d(x, K_g))) == relu(tanh(conv3d(x, sum_g lambda_g K_g)))  (equal to
+// 5e-16 in the reference's own fp64; core/models/SCENE_Net.py:322-339).  When the per-kernel bank activations are not
+// asked for, the 16-kernel contraction collapses to ONE kernel K* = sum_g lambda_g K_g, and a single-kernel 3-D
+// correlation maps onto MFMA through the Toeplitz structure along y:
+//
+//     out[z][x][y0+m] = sum_{dz,dx} sum_{y'} T_{dz,dx}[m][y'] * X[z+dz][x+dx][y0+y'],   T[m][y'] = K*[dz][dx][y'-m]
+//
+// M = 16 consecutive output y (m), N = 16 output rows (x), K = the 32-byte window y' of a kernel row (dz,dx), two
+// kernel rows per v_mfma_i32_16x16x64_i8.  The B operand is then 16 CONSECUTIVE, 16-byte aligned halo bytes per
+// lane (one ds_read_b128; no byte-shifted copies), the A operand a precomputed banded Toeplitz table of the three
+// balanced base-256 digits of the 24-bit fixed-point K* (exact int32 accumulation, as in conv_i8.hip).
+// Executed matrix work per output voxel: ceil(kz*kx/2) * 3 MFMAs per 256 outputs = 0.48 MFMA/voxel at 9^3, against
+// 3 MFMA/voxel for the 16-kernel contraction.
+//
+// Bound: MFMA (int8) with LDS well below its limit: per step a wave reads 3 + 4 ds_read_b128 for 12 MFMAs.
+#include "common.h"
+
+namespace sn {
+int conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
+                   int kx, int ky, void* out, int out_dtype, hipStream_t stream);
+}
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+__device__ __forceinline__ float relu_nan(float v) { return (v > 0.0f || v != v) ? v : 0.0f; }
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int TZ = 8, TX = 16, TY = 64;  // workgroup tile: one z plane per wave, 16 rows (N), 4 strips of 16 y (M)
+constexpr int YB = 80;                   // halo row stride in bytes (64 + 16), a multiple of 16
+constexpr int kMaxLds = 160 * 1024;
+
+struct LinShape {
+    int B, Z, X, Y, G;
+    int kz, kx, ky, pz, px, py;
+    int nzt, nxt, nyt, ntiles;
+    int npairs, nsteps;   // kernel rows (dz,dx); MFMA steps = ceil(npairs / 2)
+    int XP, rows;         // halo rows per z plane, total halo rows
+    int PYA;              // halo origin in y = y0 - PYA, PYA = roundup(py, 4) (aligned global dwords)
+};
+
+template <typename OT>
+__global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __restrict__ x,
+                                                               const float* __restrict__ bank,
+                                                               const float* __restrict__ lambdas, LinShape s,
+                                                               OT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps][3][64]
+    int* boff = reinterpret_cast<int*>(At + (size_t)s.nsteps * 3 * 64);         // [nsteps][4] halo byte offset per q
+    float* misc = reinterpret_cast<float*>(boff + s.nsteps * 4);                // [16]: scale, per-wave maxima
+    uint8_t* halo = reinterpret_cast<uint8_t*>(misc + 16);                      // [rows][YB]
+    float* kstar = reinterpret_cast<float*>(halo);                              // [ntaps] (prologue only; aliases halo)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int ntaps = s.kz * s.kx * s.ky;
+
+    // ---- prologue: K* = sum_g lambda_g K_g, its 24-bit fixed point, the Toeplitz digit table
+    float mx = 0.0f;
+    for (int t = tid; t < ntaps; t += kThreads) {
+        float a = 0.0f;
+        for (int g = 0; g < s.G; ++g) a = fmaf(lambdas[g], bank[(size_t)g * ntaps + t], a);
+        kstar[t] = a;
+        const float aa = fabsf(a);
+        mx = (aa <= 3.0e38f) ? fmaxf(mx, aa) : __int_as_float(0x7fc00000);  // NaN / inf poisons the kernel
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(mx, o, 64);
+        mx = (mx != mx || u != u) ? __int_as_float(0x7fc00000) : fmaxf(mx, u);
+    }
+    float* wmax = misc + 4;  // no static __shared__: the kernel asks for the whole 160 KiB dynamically
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    int F = 0;
+    {
+        float m = 0.0f;
+        for (int w = 0; w < kWaves; ++w) m = (m != m || wmax[w] != wmax[w]) ? __int_as_float(0x7fc00000) : fmaxf(m, wmax[w]);
+        int e = 0;
+        if (m > 0.0f) (void)frexpf(m, &e);   // m <= 2^e
+        F = 22 - e;
+        if (tid == 0) misc[0] = (m != m) ? m : ldexpf(1.0f, -F);
+    }
+    const float twoF = ldexpf(1.0f, F);
+    for (int i = tid; i < s.nsteps * 64; i += kThreads) {
+        const int st = i >> 6, l = i & 63;
+        const int m = l & 15, qq = l >> 4;
+        const int p = 2 * st + (qq >> 1);
+        uint32_t w[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        if (p < s.npairs) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int dy = 16 * (qq & 1) + j - m - (s.PYA - s.py);  // halo column y' holds global y0 - PYA + y'
+                if (dy >= 0 && dy < s.ky) {
+                    int Q = __float2int_rn(kstar[p * s.ky + dy] * twoF);
+                    const int d0 = ((Q + 128) & 255) - 128;
+                    Q = (Q - d0) >> 8;
+                    const int d1 = ((Q + 128) & 255) - 128;
+                    const int d2 = (Q - d1) >> 8;
+                    w[0][j >> 2] |= (uint32_t)(d0 & 255) << (8 * (j & 3));
+                    w[1][j >> 2] |= (uint32_t)(d1 & 255) << (8 * (j & 3));
+                    w[2][j >> 2] |= (uint32_t)(d2 & 255) << (8 * (j & 3));
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) At[(st * 3 + d) * 64 + l] = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
+    }
+    for (int i = tid; i < s.nsteps * 4; i += kThreads) {
+        const int st = i >> 2, qq = i & 3;
+        int p = 2 * st + (qq >> 1);
+        if (p >= s.npairs) p = s.npairs - 1;   // zero weights there; keep the read inside the halo
+        const int dz = p / s.kx, dx = p - dz * s.kx;
+        boff[i] = (dz * s.XP + dx) * YB + 16 * (qq & 1);
+    }
+    __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
+    const float scale = misc[0];
+
+    const size_t V = (size_t)s.Z * s.X * s.Y;
+    for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int y0 = (t % s.nyt) * TY; t /= s.nyt;
+        const int x0 = (t % s.nxt) * TX; t /= s.nxt;
+        const int z0 = (t % s.nzt) * TZ; t /= s.nzt;
+        const int b = t;
+        // ---- halo tile: rows (z0 - pz .. , x0 - px ..), columns y0 - PYA .. + YB, as aligned global dwords
+        {
+            constexpr int DW = YB / 4;
+            const int total = s.rows * DW;
+            constexpr int kBatch = 8;
+            for (int base = tid; base < total; base += kThreads * kBatch) {
+                uint32_t v[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {   // all loads first
+                    const int idx = base + u * kThreads;
+                    const int r = idx / DW, i = idx - r * DW;
+                    const int zz = r / s.XP, xx = r - zz * s.XP;
+                    const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
+                    v[u] = 0u;
+                    if (idx < total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
+                        v[u] = *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy);
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const int idx = base + u * kThreads;
+                    if (idx < total) reinterpret_cast<uint32_t*>(halo)[idx] = v[u];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- this wave's z plane: 4 strips x 3 digit planes of 16 y x 16 rows
+        const int lz = wave;
+        i32x4 acc[3][4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[d][v] = i32x4{0, 0, 0, 0};
+        const uint8_t* hb = halo + (lz * s.XP + n) * YB;
+        for (int st = 0; st < s.nsteps; ++st) {
+            const uint4 a0 = At[(st * 3 + 0) * 64 + lane], a1 = At[(st * 3 + 1) * 64 + lane],
+                        a2 = At[(st * 3 + 2) * 64 + lane];
+            const uint8_t* bp = hb + boff[st * 4 + q];
+            uint4 xv[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xv[v] = *reinterpret_cast<const uint4*>(bp + 16 * v);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                acc[0][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a0, *(const i32x4*)&xv[v], acc[0][v], 0, 0, 0);
+                acc[1][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a1, *(const i32x4*)&xv[v], acc[1][v], 0, 0, 0);
+                acc[2][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a2, *(const i32x4*)&xv[v], acc[2][v], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: D[m = 4 q + i][n]: lane holds 4 consecutive y of row x0 + n
+        const int gz = z0 + lz, gx = x0 + n;
+        if (gz < s.Z && gx < s.X) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gy = y0 + 16 * v + 4 * q;
+                float r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int low = acc[1][v][i] * 256 + acc[0][v][i];
+                    r[i] = relu_nan(tanhf(fmaf((float)acc[2][v][i], 65536.0f, (float)low) * scale));
+                }
+                OT* o = out + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
+                if (gy + 3 < s.Y) {
+                    if constexpr (sizeof(OT) == 4) {
+                        *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+                    } else {
+                        reinterpret_cast<double2*>(o)[0] = make_double2((double)r[0], (double)r[1]);
+                        reinterpret_cast<double2*>(o)[1] = make_double2((double)r[2], (double)r[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (gy + i < s.Y) o[i] = (OT)r[i];
+                }
+            }
+        }
+        __syncthreads();   // every wave is done with the halo before the next tile overwrites it
+    }
+}
+
+int num_cus() {
+    static thread_local int cached = 0;
+    if (!cached) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cached = p.multiProcessorCount;
+        if (cached <= 0) cached = 256;
+    }
+    return cached;
+}
+
+}  // namespace
+
+// returns SN_ERR_UNSUPPORTED (without touching the error text) when the shape is outside this kernel
+int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
+                       int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream) {
+    if (Y % 4 != 0 || ((uintptr_t)x % 4) || ((uintptr_t)out % 16)) return SN_ERR_UNSUPPORTED;
+    LinShape s;
+    s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G;
+    s.kz = kz; s.kx = kx; s.ky = ky;
+    s.pz = (kz - 1) / 2; s.px = (kx - 1) / 2; s.py = (ky - 1) / 2;
+    s.PYA = (s.py + 3) & ~3;
+    if (s.PYA - s.py + 15 + ky - 1 >= 32) return SN_ERR_UNSUPPORTED;  // a 16-y strip's window must fit 32 halo bytes
+    if (TY - 16 + 32 > YB) return SN_ERR_UNSUPPORTED;
+    s.nzt = (Z + TZ - 1) / TZ; s.nxt = (X + TX - 1) / TX; s.nyt = (Y + TY - 1) / TY;
+    const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
+    if (nt > 0x7fffffff) return SN_ERR_UNSUPPORTED;
+    s.ntiles = (int)nt;
+    s.npairs = kz * kx;
+    s.nsteps = (s.npairs + 1) / 2;
+    s.XP = TX + kx - 1;
+    s.rows = (TZ + kz - 1) * s.XP;
+    const size_t halo = (size_t)s.rows * YB;
+    const size_t kst = (size_t)kz * kx * ky * sizeof(float);
+    const size_t lds = (size_t)s.nsteps * 3 * 64 * 16 + (size_t)s.nsteps * 4 * 4 + 64 + (halo > kst ? halo : kst) + 16;
+    if (lds > (size_t)kMaxLds) return SN_ERR_UNSUPPORTED;
+    int grid = num_cus();
+    if (grid > s.ntiles) grid = s.ntiles;
+#define SN_LAUNCH_LIN(OT)                                                                                         \
+    do {                                                                                                          \
+        auto kern = conv_lin_i8_kernel<OT>;                                                                       \
+        if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                     \
+            return sn::check_launch("sn_conv_fused(hipFuncSetAttribute)");                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (OT*)out);         \
+    } while (0)
+    if (out_dtype == SN_F32) SN_LAUNCH_LIN(float);
+    else if (out_dtype == SN_F64) SN_LAUNCH_LIN(double);
+    else return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: out_dtype %d", out_dtype);
+#undef SN_LAUNCH_LIN
+    return sn::check_launch("sn_conv_fused");
+}
+
+extern "C" int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,
+                             int Y, int G, int kz, int kx, int ky, void* out, int out_dtype, sn_stream_t stream) {
+    if (!x || !bank || !lambdas || !out) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: null pointer");
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: non-positive extent");
+    if (x_dtype != SN_OCC8)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused: binary occupancy (SN_OCC8) input only; use sn_conv_bank");
+    const int rc = sn::conv_fused_lin((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, out, out_dtype,
+                                      sn::as_stream(stream));
+    if (rc == SN_ERR_UNSUPPORTED)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused: shape outside the kernel (Y %% 4, ky window, LDS); use "
+                                            "sn_conv_bank");
+    return rc;
+}

@@ -308,3 +308,85 @@ def test_skip_empty_tiles_option_changes_nothing_but_time(hip_device):
     assert a2.abs().max().item() == 0 and o2.abs().max().item() == 0
     with pytest.raises(sna.HipLibraryError):
         _hip.set_option("no_such_option", 1)
+
+
+# ------------------------------------------------------------------ forward through linearity (sn_conv_fused)
+@pytest.mark.parametrize("tag", ["ckpt955", "c1_999", "g16_999", "even_656"])
+def test_golden_forward_fused_linear(hip_device, golden_dir, tag):
+    """relu(tanh(conv3d(x, sum_g lambda_g K_g))) on the reference's golden forward cases: same output within 1e-4."""
+    F = np.load(os.path.join(golden_dir, "geneo_forward.npz"))
+    names = [str(n) for n in F[f"{tag}/names"]]
+    bank = torch.from_numpy(F[f"{tag}/bank"][:, 0]).float().to(hip_device).contiguous()
+    lam = go.effective_lambdas(F[f"{tag}/lambdas"], int(F[f"{tag}/last"]), names).to(hip_device)
+    x = torch.from_numpy(F[f"{tag}/x"]).to(torch.bool).to(hip_device)
+    if x.shape[-1] % 4:   # the kernel reads aligned dwords along y; such grids go through sn_conv_bank
+        assert not _hip.conv_fused_supported(x, bank.shape[1:])
+        x = torch.nn.functional.pad(x, (0, 4 - x.shape[-1] % 4))
+        ref = go.conv_bank(x.double().cpu(), bank.double().cpu().unsqueeze(1))
+        ref = torch.relu(torch.tanh((lam.double().cpu().view(1, -1, 1, 1, 1) * ref).sum(1, keepdim=True))).numpy()
+    else:
+        ref = F[f"{tag}/out"]
+    assert _hip.conv_fused_supported(x, bank.shape[1:])
+    for dt in (torch.float32, torch.float64):
+        out = _hip.conv_fused(x, bank, lam, out_dtype=dt)
+        assert out.dtype == dt and out.shape == x.shape
+        e_out = (out.double().cpu() - torch.from_numpy(ref)).abs().max().item()
+        print(tag, "fused out err", e_out)
+        assert e_out < TOL
+
+
+@pytest.mark.parametrize("shape,ks,G", [
+    ((2, 1, 16, 16, 16), (9, 9, 9), 16),
+    ((1, 1, 13, 9, 72), (9, 9, 9), 16),      # ragged z/x, y > 64 (two y tiles)
+    ((3, 1, 8, 10, 36), (9, 5, 5), 3),
+    ((1, 1, 20, 6, 132), (6, 5, 6), 5),      # even dims: pad left (k-1)//2, right k//2
+    ((2, 1, 5, 4, 4), (3, 3, 3), 1),         # grid smaller than the halo
+    ((1, 1, 9, 9, 12), (1, 1, 1), 2),        # pointwise
+    ((1, 1, 12, 12, 12), (5, 7, 3), 7),
+    ((1, 1, 7, 19, 40), (3, 3, 12), 4),      # window 15 + 11 + (8 - 5) = 29 < 32
+    ((1, 1, 7, 19, 40), (3, 3, 17), 2),      # widest ky: window 15 + 16 = 31
+    ((1, 1, 9, 33, 64), (9, 9, 9), 33),      # any G: the bank is combined before the convolution
+    ((2, 1, 17, 17, 128), (9, 9, 9), 16),
+])
+def test_fused_linear_against_oracle_and_dense_kernel(hip_device, shape, ks, G):
+    torch.manual_seed(hash((shape, ks, G)) % 2**31)
+    occ = torch.rand(shape) < 0.3
+    bank = _rand_bank(G, ks, 5, "cpu") * torch.logspace(-2, 0.5, G).view(G, 1, 1, 1)
+    lam = (torch.rand(G) - 0.3) / G
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    x = occ.to(hip_device)
+    assert _hip.conv_fused_supported(x, ks)
+    out = _hip.conv_fused(x, bank.to(hip_device).contiguous(), lam.to(hip_device))
+    assert (out.cpu().double() - ref_out).abs().max().item() < TOL
+    _, dense = _hip.conv_bank(x, bank.to(hip_device).contiguous(), lam.to(hip_device), want_act=False, want_out=True)
+    assert (out - dense).abs().max().item() < 2e-5      # two fixed-point roundings of different weights
+    assert torch.equal(out, _hip.conv_fused(x, bank.to(hip_device).contiguous(), lam.to(hip_device)))  # deterministic
+
+
+def test_fused_linear_rejects_what_it_does_not_serve(hip_device):
+    bank = _rand_bank(2, (3, 3, 3), 1, hip_device).contiguous()
+    lam = torch.tensor([0.5, 0.5], device=hip_device)
+    with pytest.raises(sna.HipLibraryError, match="SN_OCC8|occupancy"):
+        _hip.conv_fused(torch.rand((1, 1, 8, 8, 8), device=hip_device), bank, lam)          # not binary occupancy
+    x = torch.rand((1, 1, 6, 6, 30), device=hip_device) < 0.5                                 # Y % 4 != 0
+    assert not _hip.conv_fused_supported(x, (3, 3, 3))
+    with pytest.raises(sna.HipLibraryError, match="sn_conv_bank"):
+        _hip.conv_fused(x, bank, lam)
+    assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 40), dtype=torch.bool), (3, 3, 19))  # ky > window
+
+
+def test_fused_linear_full_size_equals_dense_kernel(hip_device):
+    """BASELINE C2 size: the linear path and the 16-kernel contraction agree to 2e-5 everywhere."""
+    from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec
+    specs, names, lambdas, last = synthetic_bank_spec({"cy": 6, "cone": 5, "neg": 5})
+    torch.manual_seed(0)
+    model = sna.SceneNet({"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9))
+    apply_bank_spec(model, specs, names, lambdas, last)
+    model = model.to(hip_device)
+    bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+    x = torch.rand((32, 1, 64, 64, 64), device=hip_device) < 0.035
+    _, dense = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True)
+    fused = _hip.conv_fused(x, bank, lam)
+    assert (fused - dense).abs().max().item() < 2e-5
+    assert fused.min().item() >= 0.0 and fused.max().item() < 1.0
