@@ -16,6 +16,7 @@
 //
 // Bound: MFMA (int8) with LDS well below its limit: per step a wave reads 3 + 4 ds_read_b128 for 12 MFMAs.
 #include "common.h"
+#include <cstdlib>
 
 namespace sn {
 int conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
@@ -28,10 +29,21 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 __device__ __forceinline__ float relu_nan(float v) { return (v > 0.0f || v != v) ? v : 0.0f; }
 
+// relu(tanh(v)): 0 for v <= 0, else 1 - 2 / (exp(2v) + 1) on the hardware exp / rcp (abs. error ~2e-7, inside the
+// 1e-4 bar; the 16-kernel kernels call tanhf).  NaN stays NaN like torch.relu(torch.tanh(.)); +inf -> 1.
+__device__ __forceinline__ float relu_tanh(float v) {
+    if (v != v) return v;
+    if (!(v > 0.0f)) return 0.0f;
+    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
+}
+
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int TZ = 8, TX = 16, TY = 64;  // workgroup tile: one z plane per wave, 16 rows (N), 4 strips of 16 y (M)
-constexpr int YB = 80;                   // halo row stride in bytes (64 + 16), a multiple of 16
+constexpr int YB = 80;                   // halo bytes per row (64 + 16) = 5 chunks of 16 bytes
+// The halo is stored CHUNK-MAJOR, [chunk c][row r] x 16 bytes with the rows padded to a multiple of 16: the 16 lanes
+// one ds_read_b128 cycle serves (8 with a window's first chunk, 8 with its second) then fall on 16 distinct 16-byte
+// bank groups.
 constexpr int kMaxLds = 160 * 1024;
 
 struct LinShape {
@@ -39,8 +51,9 @@ struct LinShape {
     int kz, kx, ky, pz, px, py;
     int nzt, nxt, nyt, ntiles;
     int npairs, nsteps;   // kernel rows (dz,dx); MFMA steps = ceil(npairs / 2)
-    int XP, rows;         // halo rows per z plane, total halo rows
+    int XP, rows, NRP;    // halo rows per z plane, total halo rows, rows padded to a multiple of 16
     int PYA;              // halo origin in y = y0 - PYA, PYA = roundup(py, 4) (aligned global dwords)
+    int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 8 no halo
 };
 
 template <typename OT>
@@ -49,10 +62,9 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
                                                                const float* __restrict__ lambdas, LinShape s,
                                                                OT* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps][3][64]
-    int* boff = reinterpret_cast<int*>(At + (size_t)s.nsteps * 3 * 64);         // [nsteps][4] halo byte offset per q
-    float* misc = reinterpret_cast<float*>(boff + s.nsteps * 4);                // [16]: scale, per-wave maxima
-    uint8_t* halo = reinterpret_cast<uint8_t*>(misc + 16);                      // [rows][YB]
+    uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps + 1][3][64], last step zero
+    float* misc = reinterpret_cast<float*>(At + (size_t)(s.nsteps + 1) * 3 * 64);                // [16]: scale, per-wave maxima
+    uint8_t* halo = reinterpret_cast<uint8_t*>(misc + 16);                      // [NC][NRP] x 16 bytes
     float* kstar = reinterpret_cast<float*>(halo);                              // [ntaps] (prologue only; aliases halo)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         if (tid == 0) misc[0] = (m != m) ? m : ldexpf(1.0f, -F);
     }
     const float twoF = ldexpf(1.0f, F);
-    for (int i = tid; i < s.nsteps * 64; i += kThreads) {
+    for (int i = tid; i < (s.nsteps + 1) * 64; i += kThreads) {
         const int st = i >> 6, l = i & 63;
         const int m = l & 15, qq = l >> 4;
         const int p = 2 * st + (qq >> 1);
@@ -110,48 +122,57 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #pragma unroll
         for (int d = 0; d < 3; ++d) At[(st * 3 + d) * 64 + l] = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
     }
-    for (int i = tid; i < s.nsteps * 4; i += kThreads) {
-        const int st = i >> 2, qq = i & 3;
-        int p = 2 * st + (qq >> 1);
-        if (p >= s.npairs) p = s.npairs - 1;   // zero weights there; keep the read inside the halo
-        const int dz = p / s.kx, dx = p - dz * s.kx;
-        boff[i] = (dz * s.XP + dx) * YB + 16 * (qq & 1);
-    }
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
     const float scale = misc[0];
+    if (s.dbg & 1) return;
 
     const size_t V = (size_t)s.Z * s.X * s.Y;
-    for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
-        int t = tile;
-        const int y0 = (t % s.nyt) * TY; t /= s.nyt;
-        const int x0 = (t % s.nxt) * TX; t /= s.nxt;
-        const int z0 = (t % s.nzt) * TZ; t /= s.nzt;
-        const int b = t;
-        // ---- halo tile: rows (z0 - pz .. , x0 - px ..), columns y0 - PYA .. + YB, as aligned global dwords
-        {
-            constexpr int DW = YB / 4;
-            const int total = s.rows * DW;
-            constexpr int kBatch = 8;
-            for (int base = tid; base < total; base += kThreads * kBatch) {
-                uint32_t v[kBatch];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {   // all loads first
-                    const int idx = base + u * kThreads;
-                    const int r = idx / DW, i = idx - r * DW;
-                    const int zz = r / s.XP, xx = r - zz * s.XP;
-                    const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
-                    v[u] = 0u;
-                    if (idx < total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
-                        v[u] = *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy);
-                }
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int idx = base + u * kThreads;
-                    if (idx < total) reinterpret_cast<uint32_t*>(halo)[idx] = v[u];
-                }
-            }
+    // halo rows (z0 - pz .., x0 - px ..), columns y0 - PYA .. + YB, read as aligned global dwords into registers
+    // (kHaloRegs per thread; larger halos take a synchronous remainder pass)
+    constexpr int DW = YB / 4;
+    constexpr int kHaloRegs = 16;
+    const int halo_total = s.rows * DW;
+    uint32_t hreg[kHaloRegs];
+    auto tile_origin = [&](int tl, int& b, int& z0, int& x0, int& y0) {
+        y0 = (tl % s.nyt) * TY; tl /= s.nyt;
+        x0 = (tl % s.nxt) * TX; tl /= s.nxt;
+        z0 = (tl % s.nzt) * TZ; tl /= s.nzt;
+        b = tl;
+    };
+    auto halo_load = [&](int b, int z0, int x0, int y0, int idx) -> uint32_t {
+        const int r = idx / DW, i = idx - r * DW;
+        const int zz = r / s.XP, xx = r - zz * s.XP;
+        const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
+        if (idx < halo_total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
+            return *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy);
+        return 0u;
+    };
+    auto halo_store = [&](int idx, uint32_t v) {
+        if (idx < halo_total) {
+            const int r = idx / DW, i = idx - r * DW;
+            reinterpret_cast<uint32_t*>(halo)[((i >> 2) * s.NRP + r) * 4 + (i & 3)] = v;
         }
+    };
+    int hb_b = 0, hb_z0 = 0, hb_x0 = 0, hb_y0 = 0;   // tile the registers belong to
+    auto halo_issue = [&](int tl) {
+        tile_origin(tl, hb_b, hb_z0, hb_x0, hb_y0);
+#pragma unroll
+        for (int u = 0; u < kHaloRegs; ++u) hreg[u] = halo_load(hb_b, hb_z0, hb_x0, hb_y0, tid + u * kThreads);
+    };
+    auto halo_commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < kHaloRegs; ++u) halo_store(tid + u * kThreads, hreg[u]);
+        for (int base = tid + kHaloRegs * kThreads; base < halo_total; base += kThreads)   // halos beyond the registers
+            halo_store(base, halo_load(hb_b, hb_z0, hb_x0, hb_y0, base));
+    };
+    for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
+        int b, z0, x0, y0;
+        tile_origin(tile, b, z0, x0, y0);
+        // ---- halo tile: committed from registers requested during the previous tile's MFMA loop
+        if (tile == (int)blockIdx.x) halo_issue(tile);
+        halo_commit();
         __syncthreads();
+        if (tile + (int)gridDim.x < s.ntiles) halo_issue(tile + gridDim.x);   // lands while the MFMAs below run
 
         // ---- this wave's z plane: 4 strips x 3 digit planes of 16 y x 16 rows
         const int lz = wave;
@@ -160,24 +181,60 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[d][v] = i32x4{0, 0, 0, 0};
-        const uint8_t* hb = halo + (lz * s.XP + n) * YB;
-        for (int st = 0; st < s.nsteps; ++st) {
-            const uint4 a0 = At[(st * 3 + 0) * 64 + lane], a1 = At[(st * 3 + 1) * 64 + lane],
-                        a2 = At[(st * 3 + 2) * 64 + lane];
-            const uint8_t* bp = hb + boff[st * 4 + q];
-            uint4 xv[4];
+        const uint8_t* hb = halo + (lz * s.XP + n) * 16;
+        // software pipeline, two register sets: the operands of step st + 1 are requested before the 12 MFMAs of
+        // step st issue; the halo offset of a step comes from registers (dz, dx advance by two kernel rows per step)
+        const int nst = (s.dbg & 2) ? 0 : s.nsteps;   // even
+        int pdz = 0, pdx = (q >> 1);                 // kernel row p = 2 st + (q >> 1) of this lane group
+        if (pdx >= s.kx) { pdx -= s.kx; ++pdz; }   // kx == 1
+        const int hoff = (q & 1) * s.NRP * 16;   // the window's second chunk is one chunk plane further
+        const int cstride = s.NRP * 16;
+        auto row_off = [&]() -> int {
+            const int dzc = pdz < s.kz ? pdz : s.kz - 1, dxc = pdz < s.kz ? pdx : s.kx - 1;  // past the end: zero weights
+            return (dzc * s.XP + dxc) * 16 + hoff;
+        };
+        auto advance = [&]() {   // two kernel rows on, branch-free (2 <= 2 kx: at most two wraps)
+            pdx += 2;
+            int w = pdx >= s.kx;
+            pdx -= w ? s.kx : 0;
+            pdz += w;
+            w = pdx >= s.kx;
+            pdx -= w ? s.kx : 0;
+            pdz += w;
+        };
+        uint4 aA[3], xA[4], aB[3], xB[4];
+        auto load_step = [&](int st, uint4 (&a)[3], uint4 (&xv)[4]) {
+            const uint8_t* bp = hb + row_off();
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xv[v] = *reinterpret_cast<const uint4*>(bp + 16 * v);
+            for (int d = 0; d < 3; ++d) a[d] = At[(st * 3 + d) * 64 + lane];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                acc[0][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a0, *(const i32x4*)&xv[v], acc[0][v], 0, 0, 0);
-                acc[1][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a1, *(const i32x4*)&xv[v], acc[1][v], 0, 0, 0);
-                acc[2][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a2, *(const i32x4*)&xv[v], acc[2][v], 0, 0, 0);
-            }
+            for (int v = 0; v < 4; ++v) xv[v] = *reinterpret_cast<const uint4*>(bp + v * cstride);
+            advance();
+        };
+        auto mma_step = [&](const uint4 (&a)[3], const uint4 (&xv)[4]) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const i32x4*)&a[d], *(const i32x4*)&xv[v],
+                                                                      acc[d][v], 0, 0, 0);
+        };
+        // the table holds an even number of steps plus one all-zero step, so the loop body is branch-free: a join
+        // between "prefetched" and "did not prefetch" paths would make hipcc wait for the NEW loads (lgkmcnt(3))
+        load_step(0, aA, xA);
+        for (int st = 0; st < nst; st += 2) {
+            load_step(st + 1, aB, xB);
+            __builtin_amdgcn_sched_barrier(0);   // keep the requests of the next step ahead of this step's MFMAs
+            mma_step(aA, xA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(st + 2, aA, xA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(aB, xB);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue: D[m = 4 q + i][n]: lane holds 4 consecutive y of row x0 + n
         const int gz = z0 + lz, gx = x0 + n;
-        if (gz < s.Z && gx < s.X) {
+        if (gz < s.Z && gx < s.X && !(s.dbg & 4)) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int gy = y0 + 16 * v + 4 * q;
@@ -185,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int low = acc[1][v][i] * 256 + acc[0][v][i];
-                    r[i] = relu_nan(tanhf(fmaf((float)acc[2][v][i], 65536.0f, (float)low) * scale));
+                    r[i] = relu_tanh(fmaf((float)acc[2][v][i], 65536.0f, (float)low) * scale);
                 }
                 OT* o = out + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
                 if (gy + 3 < s.Y) {
@@ -235,15 +292,17 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     if (nt > 0x7fffffff) return SN_ERR_UNSUPPORTED;
     s.ntiles = (int)nt;
     s.npairs = kz * kx;
-    s.nsteps = (s.npairs + 1) / 2;
+    s.nsteps = ((s.npairs + 1) / 2 + 1) & ~1;   // even (branch-free two-set software pipeline)
     s.XP = TX + kx - 1;
     s.rows = (TZ + kz - 1) * s.XP;
-    const size_t halo = (size_t)s.rows * YB;
+    s.NRP = (s.rows + 15) & ~15;
+    const size_t halo = (size_t)s.NRP * YB;
     const size_t kst = (size_t)kz * kx * ky * sizeof(float);
-    const size_t lds = (size_t)s.nsteps * 3 * 64 * 16 + (size_t)s.nsteps * 4 * 4 + 64 + (halo > kst ? halo : kst) + 16;
+    const size_t lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (halo > kst ? halo : kst) + 16;
     if (lds > (size_t)kMaxLds) return SN_ERR_UNSUPPORTED;
     int grid = num_cus();
     if (grid > s.ntiles) grid = s.ntiles;
+    s.dbg = getenv("SN_CONV_LIN_DBG") ? atoi(getenv("SN_CONV_LIN_DBG")) : 0;
 #define SN_LAUNCH_LIN(OT)                                                                                         \
     do {                                                                                                          \
         auto kern = conv_lin_i8_kernel<OT>;                                                                       \
