@@ -222,16 +222,24 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         // the table holds an even number of steps plus one all-zero step, so the loop body is branch-free: a join
         // between "prefetched" and "did not prefetch" paths would make hipcc wait for the NEW loads (lgkmcnt(3))
         load_step(0, aA, xA);
+        __builtin_amdgcn_sched_barrier(0);
+        // per step: the 7 LDS requests of the next step are spread between this step's 12 MFMAs (2 MFMAs, 1 read, ...)
+#define SN_LIN_G(NR)                                                                                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#define SN_LIN_INTERLEAVE() SN_LIN_G(2) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1)
         for (int st = 0; st < nst; st += 2) {
             load_step(st + 1, aB, xB);
-            __builtin_amdgcn_sched_barrier(0);   // keep the requests of the next step ahead of this step's MFMAs
             mma_step(aA, xA);
+            SN_LIN_INTERLEAVE()
             __builtin_amdgcn_sched_barrier(0);
             load_step(st + 2, aA, xA);
-            __builtin_amdgcn_sched_barrier(0);
             mma_step(aB, xB);
+            SN_LIN_INTERLEAVE()
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef SN_LIN_INTERLEAVE
+#undef SN_LIN_G
         // ---- epilogue: D[m = 4 q + i][n]: lane holds 4 consecutive y of row x0 + n
         const int gz = z0 + lz, gx = x0 + n;
         if (gz < s.Z && gx < s.X && !(s.dbg & 4)) {
