@@ -71,6 +71,47 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     const int n = lane & 15, q = lane >> 4;
     const int ntaps = s.kz * s.kx * s.ky;
 
+    const size_t V = (size_t)s.Z * s.X * s.Y;
+    // halo rows (z0 - pz .., x0 - px ..), columns y0 - PYA .. + YB, read as aligned global dwords into registers
+    // (kHaloRegs per thread; larger halos take a synchronous remainder pass)
+    constexpr int DW = YB / 4;
+    constexpr int kHaloRegs = 16;
+    const int halo_total = s.rows * DW;
+    uint32_t hreg[kHaloRegs];
+    auto tile_origin = [&](int tl, int& b, int& z0, int& x0, int& y0) {
+        y0 = (tl % s.nyt) * TY; tl /= s.nyt;
+        x0 = (tl % s.nxt) * TX; tl /= s.nxt;
+        z0 = (tl % s.nzt) * TZ; tl /= s.nzt;
+        b = tl;
+    };
+    auto halo_load = [&](int b, int z0, int x0, int y0, int idx) -> uint32_t {
+        const int r = idx / DW, i = idx - r * DW;
+        const int zz = r / s.XP, xx = r - zz * s.XP;
+        const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
+        if (idx < halo_total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
+            return *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy);
+        return 0u;
+    };
+    auto halo_store = [&](int idx, uint32_t v) {
+        if (idx < halo_total) {
+            const int r = idx / DW, i = idx - r * DW;
+            reinterpret_cast<uint32_t*>(halo)[((i >> 2) * s.NRP + r) * 4 + (i & 3)] = v;
+        }
+    };
+    int hb_b = 0, hb_z0 = 0, hb_x0 = 0, hb_y0 = 0;   // tile the registers belong to
+    auto halo_issue = [&](int tl) {
+        tile_origin(tl, hb_b, hb_z0, hb_x0, hb_y0);
+#pragma unroll
+        for (int u = 0; u < kHaloRegs; ++u) hreg[u] = halo_load(hb_b, hb_z0, hb_x0, hb_y0, tid + u * kThreads);
+    };
+    auto halo_commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < kHaloRegs; ++u) halo_store(tid + u * kThreads, hreg[u]);
+        for (int base = tid + kHaloRegs * kThreads; base < halo_total; base += kThreads)   // halos beyond the registers
+            halo_store(base, halo_load(hb_b, hb_z0, hb_x0, hb_y0, base));
+    };
+    if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);   // the first tile's halo travels while the tables are built
+
     // ---- prologue: K* = sum_g lambda_g K_g, its 24-bit fixed point, the Toeplitz digit table
     float mx = 0.0f;
     for (int t = tid; t < ntaps; t += kThreads) {
@@ -126,50 +167,10 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     const float scale = misc[0];
     if (s.dbg & 1) return;
 
-    const size_t V = (size_t)s.Z * s.X * s.Y;
-    // halo rows (z0 - pz .., x0 - px ..), columns y0 - PYA .. + YB, read as aligned global dwords into registers
-    // (kHaloRegs per thread; larger halos take a synchronous remainder pass)
-    constexpr int DW = YB / 4;
-    constexpr int kHaloRegs = 16;
-    const int halo_total = s.rows * DW;
-    uint32_t hreg[kHaloRegs];
-    auto tile_origin = [&](int tl, int& b, int& z0, int& x0, int& y0) {
-        y0 = (tl % s.nyt) * TY; tl /= s.nyt;
-        x0 = (tl % s.nxt) * TX; tl /= s.nxt;
-        z0 = (tl % s.nzt) * TZ; tl /= s.nzt;
-        b = tl;
-    };
-    auto halo_load = [&](int b, int z0, int x0, int y0, int idx) -> uint32_t {
-        const int r = idx / DW, i = idx - r * DW;
-        const int zz = r / s.XP, xx = r - zz * s.XP;
-        const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
-        if (idx < halo_total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
-            return *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy);
-        return 0u;
-    };
-    auto halo_store = [&](int idx, uint32_t v) {
-        if (idx < halo_total) {
-            const int r = idx / DW, i = idx - r * DW;
-            reinterpret_cast<uint32_t*>(halo)[((i >> 2) * s.NRP + r) * 4 + (i & 3)] = v;
-        }
-    };
-    int hb_b = 0, hb_z0 = 0, hb_x0 = 0, hb_y0 = 0;   // tile the registers belong to
-    auto halo_issue = [&](int tl) {
-        tile_origin(tl, hb_b, hb_z0, hb_x0, hb_y0);
-#pragma unroll
-        for (int u = 0; u < kHaloRegs; ++u) hreg[u] = halo_load(hb_b, hb_z0, hb_x0, hb_y0, tid + u * kThreads);
-    };
-    auto halo_commit = [&]() {
-#pragma unroll
-        for (int u = 0; u < kHaloRegs; ++u) halo_store(tid + u * kThreads, hreg[u]);
-        for (int base = tid + kHaloRegs * kThreads; base < halo_total; base += kThreads)   // halos beyond the registers
-            halo_store(base, halo_load(hb_b, hb_z0, hb_x0, hb_y0, base));
-    };
     for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
         int b, z0, x0, y0;
         tile_origin(tile, b, z0, x0, y0);
         // ---- halo tile: committed from registers requested during the previous tile's MFMA loop
-        if (tile == (int)blockIdx.x) halo_issue(tile);
         halo_commit();
         __syncthreads();
         if (tile + (int)gridDim.x < s.ntiles) halo_issue(tile + gridDim.x);   // lands while the MFMAs below run
