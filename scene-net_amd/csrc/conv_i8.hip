@@ -42,7 +42,7 @@ constexpr int NV = 8;         // accumulator tiles per wave round: 2 x-rows x 4 
 constexpr int kMaxC = 6;      // chunks per kernel row: ky <= 24
 constexpr int kCopyPad = 16;  // copy stride = tile bytes + 16: the 4 copies start 4 banks apart
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kTablePad = 2;  // all-zero MFMA steps the software pipeline may prefetch
+constexpr int kTablePad = 0;  // the pipeline's look-ahead past the last step re-reads the last step (never consumed)
 
 struct Shape {
     int B, Z, X, Y, G;
@@ -52,6 +52,7 @@ struct Shape {
     int PYA, delta; // halo origin = y0 - PYA (PYA = roundup(py, 4)), delta = PYA - py
     int CB;         // bytes between the shifted copies
     int Gtot, g0, head;  // kernel group of a larger bank: act channel stride/offset; head bits (see conv.hip)
+    int XPAD;       // unused halo rows appended to every z plane (bank placement, see conv_occ_i8)
     int perm;       // tile order multiplier, coprime to ntiles
     int skip_empty; // opt-in: skip the MFMA steps of halo tiles without a set voxel (result is exactly 0)
     int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier,
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
 
-    const int ZP = s.TZ + s.kz - 1, XP = s.TX + s.kx - 1;
+    const int ZP = s.TZ + s.kz - 1, XP = s.TX + s.kx - 1 + s.XPAD;
     const int rows = ZP * XP;
     const int ntaps = s.kz * s.kx * s.ky;
     const int KT = s.KS + kTablePad;
@@ -401,8 +402,9 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 SN_SB(ca, 3, wa, 1)
                 SN_SB(cb, 0, wa, 2)
                 SN_SB(cb, 1, wa, 3)
-                load_w(st + 2, wa);
-                ca = coff[(st + 2) * 4 + q];
+                const int s2 = (st + 2 < s.KS) ? st + 2 : s.KS - 1;  // look-ahead of the last trip: discarded
+                load_w(s2, wa);
+                ca = coff[s2 * 4 + q];
                 SN_SB(cb, 2, wb, 0)
                 SN_SB(cb, 3, wb, 1)
                 SN_SB(ca, 0, wb, 2)
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
 
 size_t lds_bytes(const Shape& s, int ypb, bool stage) {
     const size_t KT = s.KS + kTablePad;
-    const size_t rows = (size_t)(s.TZ + s.kz - 1) * (s.TX + s.kx - 1);
+    const size_t rows = (size_t)(s.TZ + s.kz - 1) * (s.TX + s.kx - 1 + s.XPAD);
     const size_t halo = 4 * (size_t)s.CB + (stage ? rows * ypb + 16 : 0);
     const size_t staged_bank = (size_t)s.G * s.kz * s.kx * s.ky * sizeof(float);  // aliases the halo area
     return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
@@ -564,7 +566,21 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
             s.TZ = c[0]; s.TX = c[1];
             s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
             s.ntiles = B * s.nzt * s.nxt * s.nyt;
-            s.CB = (s.TZ + kz - 1) * (s.TX + kx - 1) * ypb + kCopyPad;
+            // The two lane groups one LDS cycle serves read kernel rows 4 list entries apart: 4 halo rows = 16 banks
+            // apart inside a z plane, but XP - kx + 4 rows apart when the pair straddles a plane.  Pad the plane
+            // with unused rows until that distance is = 16 banks (mod 32) too; at kx = 9, 80-byte rows: 16 -> 17
+            // rows ([measured] SQ_LDS_BANK_CONFLICT was 23 % of the LDS-active cycles without it).
+            s.XPAD = 0;
+            for (int pad = 0; pad < 8; ++pad) {
+                const int xp = s.TX + kx - 1 + pad;
+                const int apart = (ypb == 96) ? 2 : 4;   // slot_index: list distance of the paired lane groups
+                if (((xp - kx + apart) * (ypb / 4)) % 32 != 16) continue;
+                s.XPAD = pad;
+                s.CB = (s.TZ + kz - 1) * xp * ypb + kCopyPad;
+                if (lds_bytes(s, ypb, stage) <= (size_t)kMaxLds) break;
+                s.XPAD = 0;
+            }
+            s.CB = (s.TZ + kz - 1) * (s.TX + kx - 1 + s.XPAD) * ypb + kCopyPad;
             if (lds_bytes(s, ypb, stage) > (size_t)kMaxLds) continue;
             found = true;
             if (s.ntiles >= 4 * cus) break;
