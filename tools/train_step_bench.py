@@ -2,6 +2,7 @@
 """Training-step rates at BASELINE C2 (not the headline): voxelise(+GT) -> SceneNet forward -> GENEO_Tversky_Loss ->
 backward, with HIP-event timings per stage.  python tools/train_step_bench.py [--batch 32] [--iters 10]"""
 import argparse
+import gc
 import os
 import sys
 
@@ -14,6 +15,8 @@ from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthe
 
 
 def timed(fn, iters, warm=2):
+    gc.collect()
+    gc.freeze()   # keep Python's full GC passes out of the timed loop
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
