@@ -17,6 +17,7 @@
 // Bound: MFMA (int8) with LDS well below its limit: per step a wave reads 3 + 4 ds_read_b128 for 12 MFMAs.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace sn {
 int conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
@@ -53,7 +54,7 @@ struct LinShape {
     int npairs, nsteps;   // kernel rows (dz,dx); MFMA steps = ceil(npairs / 2)
     int XP, rows, NRP;    // halo rows per z plane, total halo rows, rows padded to a multiple of 16
     int PYA;              // halo origin in y = y0 - PYA, PYA = roundup(py, 4) (aligned global dwords)
-    int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 8 no halo
+    int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 16 no deferral
 };
 
 template <typename OT>
@@ -167,6 +168,39 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     const float scale = misc[0];
     if (s.dbg & 1) return;
 
+    // Deferred epilogue: a tile's 16 outputs per lane stay in registers as pre-activations and are finished
+    // (exp / rcp / 16-byte stores) BETWEEN the MFMAs of the next tile's first 16 steps, instead of in a phase where
+    // the matrix pipe idles.  Needs >= 16 steps; smaller kernels finish each tile at once.
+    const bool defer = s.nsteps >= 16 && !(s.dbg & 16);
+    float pv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pv[k] = 0.f;
+    OT* pout = out;      // address of strip 0's first output of the pending tile
+    int pgy = 0;         // its y
+    bool pend = false;   // a tile is pending and this lane's row is inside the grid
+    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store4 = [&](OT* o, int gy, const float (&r)[4]) {
+        if (gy + 3 < s.Y) {
+            if constexpr (sizeof(OT) == 4) {
+                *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+            } else {
+                reinterpret_cast<double2*>(o)[0] = make_double2((double)r[0], (double)r[1]);
+                reinterpret_cast<double2*>(o)[1] = make_double2((double)r[2], (double)r[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (gy + i < s.Y) o[i] = (OT)r[i];
+        }
+    };
+    auto epi_item = [&](auto K) {   // output k = 4 v + i of the pending tile
+        constexpr int k = decltype(K)::value;
+        rr[k & 3] = relu_tanh(pv[k]);
+        if constexpr ((k & 3) == 3) {
+            if (pend) store4(pout + 16 * (k >> 2), pgy + 16 * (k >> 2), rr);
+        }
+    };
+#define SN_EPI2(K) epi_item(std::integral_constant<int, (K)>{}); epi_item(std::integral_constant<int, (K) + 1>{});
     for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
         int b, z0, x0, y0;
         tile_origin(tile, b, z0, x0, y0);
@@ -229,47 +263,56 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
     __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
 #define SN_LIN_INTERLEAVE() SN_LIN_G(2) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1)
-        for (int st = 0; st < nst; st += 2) {
-            load_step(st + 1, aB, xB);
-            mma_step(aA, xA);
-            SN_LIN_INTERLEAVE()
-            __builtin_amdgcn_sched_barrier(0);
-            load_step(st + 2, aA, xA);
-            mma_step(aB, xB);
-            SN_LIN_INTERLEAVE()
-            __builtin_amdgcn_sched_barrier(0);
+#define SN_LIN_PAIR(ST)                                                                                            \
+    load_step((ST) + 1, aB, xB);                                                                                  \
+    mma_step(aA, xA);                                                                                             \
+    SN_LIN_INTERLEAVE()                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    load_step((ST) + 2, aA, xA);                                                                                  \
+    mma_step(aB, xB);                                                                                             \
+    SN_LIN_INTERLEAVE()                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+        int st0 = 0;
+        if (defer && nst >= 16) {   // block-uniform; the pending tile's outputs ride along the first 16 steps
+            SN_LIN_PAIR(0)  SN_EPI2(0)
+            SN_LIN_PAIR(2)  SN_EPI2(2)
+            SN_LIN_PAIR(4)  SN_EPI2(4)
+            SN_LIN_PAIR(6)  SN_EPI2(6)
+            SN_LIN_PAIR(8)  SN_EPI2(8)
+            SN_LIN_PAIR(10) SN_EPI2(10)
+            SN_LIN_PAIR(12) SN_EPI2(12)
+            SN_LIN_PAIR(14) SN_EPI2(14)
+            st0 = 16;
         }
+        for (int st = st0; st < nst; st += 2) {
+            SN_LIN_PAIR(st)
+        }
+#undef SN_LIN_PAIR
 #undef SN_LIN_INTERLEAVE
 #undef SN_LIN_G
         // ---- epilogue: D[m = 4 q + i][n]: lane holds 4 consecutive y of row x0 + n
         const int gz = z0 + lz, gx = x0 + n;
-        if (gz < s.Z && gx < s.X && !(s.dbg & 4)) {
+        const bool inside = gz < s.Z && gx < s.X && !(s.dbg & 4);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int gy = y0 + 16 * v + 4 * q;
-                float r[4];
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int low = acc[1][v][i] * 256 + acc[0][v][i];
-                    r[i] = relu_tanh(fmaf((float)acc[2][v][i], 65536.0f, (float)low) * scale);
-                }
-                OT* o = out + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
-                if (gy + 3 < s.Y) {
-                    if constexpr (sizeof(OT) == 4) {
-                        *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
-                    } else {
-                        reinterpret_cast<double2*>(o)[0] = make_double2((double)r[0], (double)r[1]);
-                        reinterpret_cast<double2*>(o)[1] = make_double2((double)r[2], (double)r[3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (gy + i < s.Y) o[i] = (OT)r[i];
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int low = acc[1][v][i] * 256 + acc[0][v][i];
+                pv[4 * v + i] = fmaf((float)acc[2][v][i], 65536.0f, (float)low) * scale;
             }
+        pend = inside;
+        pgy = y0 + 4 * q;
+        pout = out + (size_t)b * V + ((size_t)(inside ? gz : 0) * s.X + (inside ? gx : 0)) * s.Y + pgy;
+        if (!defer) {
+            SN_EPI2(0) SN_EPI2(2) SN_EPI2(4) SN_EPI2(6) SN_EPI2(8) SN_EPI2(10) SN_EPI2(12) SN_EPI2(14)
+            pend = false;
         }
         __syncthreads();   // every wave is done with the halo before the next tile overwrites it
     }
+    if (defer) {   // the last tile's outputs
+        SN_EPI2(0) SN_EPI2(2) SN_EPI2(4) SN_EPI2(6) SN_EPI2(8) SN_EPI2(10) SN_EPI2(12) SN_EPI2(14)
+    }
+#undef SN_EPI2
 }
 
 int num_cus() {
