@@ -1,0 +1,55 @@
+// What rate does v_mfma_i32_16x16x64_i8 sustain on an MI355X with nothing else in the loop?
+// 256 workgroups x 512 threads (2 waves per SIMD, as the conv kernels run), each wave NACC independent accumulators.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_i8_peak.hip -o /tmp/mfma_i8_peak && /tmp/mfma_i8_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+template <int NACC>
+__global__ __launch_bounds__(512) void peak_kernel(int iters, int* out) {
+    i32x4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = i32x4{0, 0, 0, 0};
+    i32x4 a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)blockIdx.x, 7};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+    }
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 0x7fffffff) out[0] = s;
+}
+
+template <int NACC>
+void run(int waves_per_simd) {
+    int* d = nullptr;
+    if (hipMalloc(&d, 4) != hipSuccess) return;
+    const int iters = 4000, threads = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    peak_kernel<NACC><<<256, threads>>>(iters, d);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    peak_kernel<NACC><<<256, threads>>>(iters, d);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double mfma = 256.0 * (threads / 64) * iters * NACC;
+    const double tops = mfma * 2.0 * 16 * 16 * 64 / (ms * 1e-3) / 1e12;
+    printf("waves/SIMD %d  accumulators %2d: %8.3f ms  %7.1f TOP/s  (%.2f cycles per MFMA per SIMD at 2.4 GHz)\n",
+           waves_per_simd, NACC, ms, tops, (ms * 1e-3 * 2.4e9) / (mfma / 1024.0));
+    (void)hipFree(d);
+}
+
+int main() {
+    for (int w : {1, 2}) {
+        run<4>(w);
+        run<12>(w);
+        run<24>(w);
+    }
+    return 0;
+}
