@@ -2,7 +2,7 @@
 """bench.py -- BASELINE.json's headline: voxel-tiles/s of the SCENE-Net GENEO forward hot path on MI355X.
 
 One step = one pass of the hot path over one HBM-resident batch of synthetic tiles:
-    bbox -> edge tables -> atomic scatter -> finalize (occupancy)      [K1, csrc/voxel.hip]
+    bbox -> (edge tables, LDS-bitmap scatter) -> finalize (occupancy) [K1, csrc/voxel.hip]
     -> GENEO bank build                                                [K2, csrc/bank.hip]
     -> bank conv on MFMA + fused convex head                           [K3, csrc/conv.hip]
 Workload = BASELINE configs[1] ("C2"): 32 tiles x 100k points, 64^3 grid, 16 GENEO kernels of 9^3, per GPU.
@@ -283,7 +283,7 @@ def main():
         g_ms = (time.perf_counter() - ts) / args.steps * 1e3
         graph_info = {"ms_per_step": g_ms, "tiles_per_s_per_gpu": B / (g_ms * 1e-3),
                       "identical_output": bool(torch.equal(out_graph, out)),
-                      "note": "whole step (5 voxel launches, bank, conv) replayed from one hipGraph"}
+                      "note": "whole step (4 voxel launches, bank, conv) replayed from one hipGraph"}
         del graph
     except Exception as exc:  # noqa: BLE001 -- an extra, never fatal to the headline
         graph_info = {"error": f"{type(exc).__name__}: {exc}"[:200]}
@@ -319,8 +319,8 @@ def main():
                           "unit": "TFLOP/s", "frac": conv32_tflops / PEAK_F32_MFMA_TFLOPS,
                           "traffic": traffic.get("conv_bank_kernel"), "launch_ms": conv32_ms,
                           "flops_per_launch": conv_flops, "tiles_per_s_conv_only": B / (conv32_ms * 1e-3)},
-        "roofline_voxel": {"kernel": "K1: bbox partials + desc + LDS-bitmap occupancy + finalize + gated fallback "
-                                     "(5 launches)", "bound": "hbm", "achieved": vox_gbs, "peak": PEAK_HBM_GBS,
+        "roofline_voxel": {"kernel": "K1: bbox partials + (descriptor derived in-kernel) LDS-bitmap occupancy + finalize + "
+                                     "gated fallback (4 launches)", "bound": "hbm", "achieved": vox_gbs, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": vox_gbs / PEAK_HBM_GBS, "traffic": traffic.get("voxel_stage"),
                            "stage_ms": vox_ms, "bytes_per_stage": vox_bytes},
         "fused_linear": fused_info,

@@ -202,6 +202,16 @@ int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* o
                        int32_t* flags, int32_t* dropped,
                        int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream);
 
+/* sn_voxel_prepare + sn_voxel_occupancy in four launches instead of five: the binning kernel derives the tile's
+ * descriptor (cube regularisation, numpy.linspace edges: the same instruction sequence, the same bits) from the bbox
+ * partials itself and publishes it in `desc` [B, SN_DESC_LEN] (and the raw box in `bbox` [B,6], nullable) for the later
+ * kernels and callers.  partial_ws: scratch [B, SN_BBOX_PARTS, 6] f64.  Everything else as sn_voxel_occupancy. */
+int sn_voxel_occupancy_fused(const double* pts, const double* labels, const int64_t* offsets, int B, int nx, int ny,
+                             int nz, int regular, const double* keep_labels_host, int n_keep, double* partial_ws,
+                             double* bbox, double* desc, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
+                             int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
+                             sn_stream_t stream);
+
 /* Grid -> points: out[c, i] = grid[b(i), c, vz, vx, vy] for every point i of the batch, binned exactly as the
  * scatter binned it (same desc); points outside the edge table get `fill`.  grid [B,channels,nz,nx,ny] and
  * out [channels, total] are of `dtype` (SN_F32 | SN_F64).  The reference only has the voxel-list direction

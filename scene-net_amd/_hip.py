@@ -39,6 +39,8 @@ SYMBOLS = {
     "sn_voxel_scatter": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "sn_voxel_finalize": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "sn_voxel_occupancy_fused": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
+                                         _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
@@ -295,6 +297,40 @@ def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[flo
                                    _ptr(counts), _ptr(towers), _stream())
     _check(rc, "sn_voxel_occupancy")
     return occ, gt_occ, flags, dropped
+
+
+def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, keep_labels: Sequence[float] = (),
+                          want_gt_occ: bool = False, out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True,
+                          want_bbox: bool = False):
+    """sn_voxel_occupancy_fused: bbox + descriptor + LDS-bitmap occupancy in four launches.  Returns
+    (occ, gt_occ | None, flags, dropped, desc, bbox | None)."""
+    B = offsets.numel() - 1
+    nx, ny, nz = (int(v) for v in n_xyz)
+    V = nx * ny * nz
+    dev = pts.device
+    planes = 2 if want_gt_occ else 1
+    partial = torch.empty((B, SN_BBOX_PARTS, 6), dtype=torch.float64, device=dev)
+    desc = torch.empty((B, desc_len(nx, ny, nz)), dtype=torch.float64, device=dev)
+    bbox = torch.empty((B, 6), dtype=torch.float64, device=dev) if want_bbox else None
+    bits = torch.empty((B * SN_OCC_PARTS * (planes * (V // 32) + 1),), dtype=torch.int32, device=dev)
+    occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev)
+    gt_occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev) if want_gt_occ else None
+    flags = torch.empty((B,), dtype=torch.int32, device=dev)
+    dropped = torch.empty((B,), dtype=torch.int32, device=dev)
+    counts = towers = None
+    if exact_fallback:
+        counts = torch.empty((B, V), dtype=torch.int32, device=dev)
+        towers = torch.empty((B, V), dtype=torch.int32, device=dev) if want_gt_occ else None
+    keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
+    rc = load().sn_voxel_occupancy_fused(_ptr(pts, torch.float64, "pts"),
+                                         _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
+                                         _ptr(offsets, torch.int64, "offsets"), B, nx, ny, nz, int(regular),
+                                         ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
+                                         _ptr(partial), _ptr(bbox), _ptr(desc), _ptr(bits), _ptr(occ), _ptr(gt_occ),
+                                         _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped), _ptr(counts), _ptr(towers),
+                                         _stream())
+    _check(rc, "sn_voxel_occupancy_fused")
+    return occ, gt_occ, flags, dropped, desc, bbox
 
 
 def gather_points(grid: torch.Tensor, pts: torch.Tensor, offsets: torch.Tensor, desc: torch.Tensor,

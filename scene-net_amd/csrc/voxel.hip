@@ -258,6 +258,63 @@ __global__ void desc_kernel(const double* __restrict__ box, int nparts, int nx, 
     }
 }
 
+// The descriptor of tile b from its partial boxes, written by the calling workgroup (nthreads threads, >= 64) into
+// `lohi` [6] and `edges` [nx+ny+nz+3] (LDS or global) -- the same instruction sequence as desc_kernel, so every
+// workgroup that derives it gets the same bits.  Ends with a __syncthreads().
+__device__ void derive_desc(const double* __restrict__ box, int nparts, int b, int nx, int ny, int nz, int regular,
+                            double* lohi, double* edges, int nthreads) {
+    __shared__ double red6[6];
+    const double* bb = box + (size_t)b * nparts * 6;
+    if (threadIdx.x < 64) {
+        for (int c = 0; c < 6; ++c) {
+            double v = (c < 3) ? DBL_MAX : -DBL_MAX;
+            for (int pp = threadIdx.x; pp < nparts; pp += 64) {
+                const double u = bb[pp * 6 + c];
+                v = (c < 3) ? fmin(v, u) : fmax(v, u);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double u = __shfl_xor(v, o, 64);
+                v = (c < 3) ? fmin(v, u) : fmax(v, u);
+            }
+            if (threadIdx.x == 0) red6[c] = v;
+        }
+    }
+    __syncthreads();
+    double lo[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = red6[c];
+        hi[c] = red6[3 + c];
+    }
+    if (regular) {
+        double r[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = __dsub_rn(hi[c], lo[c]);
+        double rmax = fmax(r[0], fmax(r[1], r[2]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double half = __ddiv_rn(__dsub_rn(rmax, r[c]), 2.0);
+            lo[c] = __dsub_rn(lo[c], half);
+            hi[c] = __dadd_rn(hi[c], half);
+        }
+    }
+    if (threadIdx.x < 3) {
+        lohi[threadIdx.x] = lo[threadIdx.x];
+        lohi[3 + threadIdx.x] = hi[threadIdx.x];
+    }
+    const int n[3] = {nx, ny, nz};
+    int base = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double step = __ddiv_rn(__dsub_rn(hi[c], lo[c]), (double)n[c]);
+        for (int k = threadIdx.x; k <= n[c]; k += nthreads)
+            edges[base + k] = (k == n[c]) ? hi[c] : __dadd_rn(__dmul_rn((double)k, step), lo[c]);
+        base += n[c] + 1;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- binning
 // largest j with e[j] < p  (== numpy.searchsorted(e, p, side='left') - 1), in [-1, n]
 __device__ __forceinline__ int bin_axis(double p, const double* e, int n, double lo, double inv_step) {
@@ -357,20 +414,47 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
                                                                   int slabs, KeepLabels keep,
                                                                   uint32_t* __restrict__ bits_ws,
                                                                   int32_t* __restrict__ dropped_parts,
-                                                                  int32_t* __restrict__ flags) {
+                                                                  int32_t* __restrict__ flags,
+                                                                  const double* __restrict__ box_parts, int nbparts,
+                                                                  int regular, double* __restrict__ desc_out,
+                                                                  double* __restrict__ bbox_out) {
     __shared__ int dropped_blk;
+    __shared__ double lohi[6];
     if (threadIdx.x == 0) dropped_blk = 0;
     extern __shared__ double smem[];
     const int ne = nx + ny + nz + 3;
     double* edges = smem;
     uint32_t* bits = reinterpret_cast<uint32_t*>(smem + ((ne + 1) & ~1));  // 16-byte aligned
     const int b = blockIdx.y;
-    const double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
     const int part = blockIdx.x / slabs, slab = blockIdx.x - part * slabs;
     const int swords = words / slabs;
     const int f_lo = slab * swords * 32, f_hi = f_lo + swords * 32;  // flat voxel range of this slab
     for (int i = threadIdx.x; i < swords * planes; i += kOccThreads) bits[i] = 0u;
-    load_edges(edges, d, ne, kOccThreads);  // ends with __syncthreads()
+    const double* d;
+    if (box_parts) {
+        // fused prepare: every workgroup derives the tile's descriptor from the partial boxes (3 (n+1) edges: cheaper
+        // than one more dependent launch); workgroup (part 0, slab 0) publishes it for the later kernels
+        derive_desc(box_parts, nbparts, b, nx, ny, nz, regular, lohi, edges, kOccThreads);
+        d = lohi;
+        if (blockIdx.x == 0) {
+            double* dd = desc_out + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+            for (int i = threadIdx.x; i < 6 + ne; i += kOccThreads) dd[i] = (i < 6) ? lohi[i] : edges[i - 6];
+            if (bbox_out) {   // the raw box (before the cube regularisation), as sn_voxel_prepare reports it
+                const double* bb = box_parts + (size_t)b * nbparts * 6;
+                if (threadIdx.x < 6) {
+                    double v = (threadIdx.x < 3) ? DBL_MAX : -DBL_MAX;
+                    for (int pp = 0; pp < nbparts; ++pp) {
+                        const double u = bb[pp * 6 + threadIdx.x];
+                        v = (threadIdx.x < 3) ? fmin(v, u) : fmax(v, u);
+                    }
+                    bbox_out[b * 6 + threadIdx.x] = v;
+                }
+            }
+        }
+    } else {
+        d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+        load_edges(edges, d, ne, kOccThreads);  // ends with __syncthreads()
+    }
     Binner bin;
     bin.init(edges, d, nx, ny, nz);
     const bool want_tower = (planes == 2);
@@ -756,11 +840,13 @@ extern "C" int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_cou
     return sn::check_launch("sn_voxel_finalize");
 }
 
-extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* offsets, int B,
-                                  const double* desc, int nx, int ny, int nz, const double* keep_labels_host,
-                                  int n_keep, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
-                                  int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
-                                  sn_stream_t stream) {
+// sn_voxel_occupancy (descriptor given) and sn_voxel_occupancy_fused (box_parts given: the binning kernel derives the
+// descriptor itself and writes it to `desc`)
+static int occupancy_impl(const double* pts, const double* labels, const int64_t* offsets, int B, double* desc, int nx,
+                          int ny, int nz, const double* keep_labels_host, int n_keep, uint32_t* bits_ws, void* occ,
+                          void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped, int32_t* counts_ws,
+                          int32_t* towers_ws, const double* box_parts, int nbparts, int regular, double* bbox_out,
+                          sn_stream_t stream) {
     if (!pts || !offsets || !desc || !bits_ws || !occ)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: null pointer");
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -804,7 +890,8 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
         if (sn::ensure_dynamic_lds((const void*)kern, 96 * 1024) != hipSuccess)
             return sn::check_launch("sn_voxel_occupancy(hipFuncSetAttribute)");
         hipLaunchKernelGGL(kern, dim3(parts * slabs, B), dim3(kOccThreads), lds1, s, pts, labels, offsets, desc, nx,
-                           ny, nz, words, planes, parts, slabs, keep, bits_ws, dropped_parts, flags);
+                           ny, nz, words, planes, parts, slabs, keep, bits_ws, dropped_parts, flags, box_parts, nbparts,
+                           regular, box_parts ? desc : nullptr, bbox_out);
     }
     const int rows = nz * nx;
     int C = (words + kThreads - 1) / kThreads;
@@ -827,6 +914,38 @@ extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const
 #undef SN_FALLBACK
     }
     return sn::check_launch("sn_voxel_occupancy");
+}
+
+extern "C" int sn_voxel_occupancy(const double* pts, const double* labels, const int64_t* offsets, int B,
+                                  const double* desc, int nx, int ny, int nz, const double* keep_labels_host,
+                                  int n_keep, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
+                                  int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
+                                  sn_stream_t stream) {
+    return occupancy_impl(pts, labels, offsets, B, const_cast<double*>(desc), nx, ny, nz, keep_labels_host, n_keep,
+                          bits_ws, occ, gt_occ, out_dtype, flags, dropped, counts_ws, towers_ws, nullptr, 0, 0, nullptr,
+                          stream);
+}
+
+extern "C" int sn_voxel_occupancy_fused(const double* pts, const double* labels, const int64_t* offsets, int B, int nx,
+                                        int ny, int nz, int regular, const double* keep_labels_host, int n_keep,
+                                        double* partial_ws, double* bbox, double* desc, uint32_t* bits_ws, void* occ,
+                                        void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                                        int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream) {
+    if (!pts || !offsets || !partial_ws || !desc)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused: null pointer");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused: non-positive extent (B=%d n=%d,%d,%d)", B, nx,
+                        ny, nz);
+    hipStream_t s = sn::as_stream(stream);
+    dim3 grid(SN_BBOX_PARTS, B);
+    if (aligned16(pts))
+        hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    else
+        hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    if (int rc = sn::check_launch("sn_voxel_occupancy_fused(bbox)")) return rc;
+    return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
+                          out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
+                          bbox, stream);
 }
 
 extern "C" int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets,

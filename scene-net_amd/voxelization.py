@@ -94,12 +94,17 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
     want_t = (want_gt or want_gt_occ)
     if want_t and (batch.labels is None or keep_labels is None):
         raise ValueError("ground-truth grids need labels and keep_labels")
+    occupancy_only = (want_occ and not (want_density or want_gt or want_counts)
+                      and _hip.occupancy_supported((nx, ny, nz), 2 if want_gt_occ else 1))
+    if occupancy_only and bounds is None:   # the hot path: bbox, descriptor, bitmap, expansion in four launches
+        occ, gt_occ, flags, dropped, desc, _ = _hip.voxel_occupancy_fused(
+            batch.pts, batch.labels if want_t else None, batch.offsets, (nx, ny, nz), True,
+            _labels_list(keep_labels) if want_t else (), want_gt_occ=want_gt_occ, out_dtype=occ_dtype)
+        return VoxelGrids(None, None, None, None, occ, gt_occ, desc, dropped, flags)
     if bounds is None:
         desc, _ = _hip.voxel_prepare(batch.pts, batch.offsets, (nx, ny, nz), regular=True)
     else:
         desc = _hip.voxel_desc(bounds, (nx, ny, nz), from_bounds=True)
-    occupancy_only = (want_occ and not (want_density or want_gt or want_counts)
-                      and _hip.occupancy_supported((nx, ny, nz), 2 if want_gt_occ else 1))
     if occupancy_only:
         occ, gt_occ, flags, dropped = _hip.voxel_occupancy(batch.pts, batch.labels if want_t else None,
                                                            batch.offsets, desc, (nx, ny, nz),
