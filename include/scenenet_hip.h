@@ -123,6 +123,16 @@ int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lam
 int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
                   int G, int kz, int kx, int ky, void* out, int out_dtype, sn_stream_t stream);
 
+/* SceneNet.forward for FLOAT grids that are usually binary occupancy -- what the reference itself feeds: f64 {0., 1.}
+ * out of ToFullDense (core/datasets/torch_transforms.py:33-34).  One pass writes (x != 0) into occ_ws [B*Z*X*Y] bytes
+ * and raises not_binary[0] when an element is neither 0 nor 1; then the int8 form (sn_conv_fused on the bytes, or
+ * sn_conv_bank where that does not serve the shape) and the fp32 form (sn_conv_bank on x) of the same forward are
+ * BOTH enqueued, each gated on that device flag: one runs, the other exits in its first instruction.  No host
+ * synchronisation, same output contract as sn_conv_bank(out only).  x: SN_F32 | SN_F64, 16-byte aligned. */
+int sn_forward_auto(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
+                    int G, int kz, int kx, int ky, uint8_t* occ_ws, int32_t* not_binary, void* out, int out_dtype,
+                    sn_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * K1  point cloud -> voxel grid
  * replaces: pyntcloud VoxelGrid.compute as called by eda.voxelize_ply

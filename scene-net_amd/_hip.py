@@ -33,6 +33,7 @@ SYMBOLS = {
     "sn_effective_lambdas": (c_int, [_P, _P, _I, _I, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sn_conv_fused": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "sn_forward_auto": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
     "sn_voxel_desc": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sn_voxel_desc_from_bounds": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
@@ -176,6 +177,22 @@ def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
                               _DT_OUT[out_dtype], _stream())
     _check(rc, "sn_conv_fused")
     return out
+
+
+def forward_auto(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor, out_dtype: Optional[torch.dtype] = None):
+    """sn_forward_auto: the forward output for a float grid; binary grids (the reference's f64 {0,1} input) take the
+    int8 path, anything else the fp32 contraction, decided on the device.  Returns (out, not_binary flag [1] i32)."""
+    B, _, Z, X, Y = x.shape
+    G, kz, kx, ky = bank.shape
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device)
+    occ = torch.empty((x.numel(),), dtype=torch.uint8, device=x.device)
+    flag = torch.empty((1,), dtype=torch.int32, device=x.device)
+    rc = load().sn_forward_auto(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                                _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky, _ptr(occ), _ptr(flag),
+                                _ptr(out), _DT_OUT[out_dtype], _stream())
+    _check(rc, "sn_forward_auto")
+    return out, flag
 
 
 def desc_len(nx: int, ny: int, nz: int) -> int:

@@ -14,6 +14,11 @@ char* error_buffer() {
 static std::atomic<int> g_skip_empty{0};
 int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
 
+static thread_local Gate g_gate{nullptr, 0};
+Gate current_gate() { return g_gate; }
+GateScope::GateScope(const int32_t* ptr, int want) { g_gate = Gate{ptr, want}; }
+GateScope::~GateScope() { g_gate = Gate{nullptr, 0}; }
+
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
     static std::mutex mu;
     static std::unordered_map<const void*, int> configured;  // per process; one device kind (gfx950)

@@ -31,4 +31,17 @@ int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 // attribute call is not a stream operation, so steady-state launches stay free of it (cheaper, graph-capturable).
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);  // cabi.hip
 
+// Device-side gate of the conv launches made by this thread while a GateScope is alive: a kernel whose shape carries
+// (gate, want) exits in its first instruction unless *gate == want (sn_forward_auto enqueues the int8 and the fp32
+// form of the same forward and lets a device flag pick one -- no host synchronisation).
+struct Gate {
+    const int32_t* ptr;
+    int want;
+};
+Gate current_gate();          // {nullptr, 0} outside a scope
+struct GateScope {
+    GateScope(const int32_t* ptr, int want);
+    ~GateScope();
+};
+
 }  // namespace sn

@@ -49,6 +49,8 @@ struct ConvShape {
     int T4;              // tap steps of 4, rounded up to even (ping-pong unroll)
     int Gtot, g0;        // this launch handles kernels g0 .. g0+G-1 of a bank of Gtot (act channel stride)
     int head;            // bit 0: add the partial sum already in `out`; bit 1: apply relu(tanh) (else store raw)
+    const int32_t* gate; // run only if null or *gate == gate_want (common.h: Gate)
+    int gate_want;
 };
 
 template <typename T>
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
                                                              const float* __restrict__ bank,
                                                              const float* __restrict__ lambdas, ConvShape s,
                                                              OT* __restrict__ act, OT* __restrict__ out) {
+    if (s.gate && *s.gate != s.gate_want) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -451,6 +454,7 @@ int sn::conv_bank_group(const void* x, int x_dtype, const float* bank, const flo
     ConvShape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
+    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
     s.T4 = (((kz * kx * ky + 3) / 4) + 1) & ~1;
     s.nyt = (Y + TY - 1) / TY;
     const int cus = num_cus();

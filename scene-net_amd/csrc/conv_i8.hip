@@ -53,6 +53,8 @@ struct Shape {
     int CB;         // bytes between the shifted copies
     int Gtot, g0, head;  // kernel group of a larger bank: act channel stride/offset; head bits (see conv.hip)
     int XPAD;       // unused halo rows appended to every z plane (bank placement, see conv_occ_i8)
+    const int32_t* gate;  // run only if null or *gate == gate_want (common.h: Gate)
+    int gate_want;
     int perm;       // tile order multiplier, coprime to ntiles
     int skip_empty; // opt-in: skip the MFMA steps of halo tiles without a set voxel (result is exactly 0)
     int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier,
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                                                                const float* __restrict__ lambdas, Shape s,
                                                                int* __restrict__ ticket, OT* __restrict__ act,
                                                                OT* __restrict__ out) {
+    if (s.gate && *s.gate != s.gate_want) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -539,6 +542,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     Shape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
+    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
     s.C = (ky + 3) / 4;
     if (s.C > kMaxC) return 1;
     s.R = kz * kx;

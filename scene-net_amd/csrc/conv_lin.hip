@@ -20,6 +20,9 @@
 #include <type_traits>
 
 namespace sn {
+int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
+                    int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                    sn_stream_t stream);   // conv.hip
 int conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
                    int kx, int ky, void* out, int out_dtype, hipStream_t stream);
 }
@@ -54,6 +57,8 @@ struct LinShape {
     int npairs, nsteps;   // kernel rows (dz,dx); MFMA steps = ceil(npairs / 2)
     int XP, rows, NRP;    // halo rows per z plane, total halo rows, rows padded to a multiple of 16
     int PYA;              // halo origin in y = y0 - PYA, PYA = roundup(py, 4) (aligned global dwords)
+    const int32_t* gate;  // run only if null or *gate == gate_want (common.h: Gate)
+    int gate_want;
     int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 16 no deferral
 };
 
@@ -62,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
                                                                const float* __restrict__ bank,
                                                                const float* __restrict__ lambdas, LinShape s,
                                                                OT* __restrict__ out) {
+    if (s.gate && *s.gate != s.gate_want) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps + 1][3][64], last step zero
     float* misc = reinterpret_cast<float*>(At + (size_t)(s.nsteps + 1) * 3 * 64);                // [16]: scale, per-wave maxima
@@ -335,6 +341,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     LinShape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G;
     s.kz = kz; s.kx = kx; s.ky = ky;
+    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
     s.pz = (kz - 1) / 2; s.px = (kx - 1) / 2; s.py = (ky - 1) / 2;
     s.PYA = (s.py + 3) & ~3;
     if (s.PYA - s.py + 15 + ky - 1 >= 32) return SN_ERR_UNSUPPORTED;  // a 16-y strip's window must fit 32 halo bytes
@@ -367,6 +374,86 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     else return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: out_dtype %d", out_dtype);
 #undef SN_LAUNCH_LIN
     return sn::check_launch("sn_conv_fused");
+}
+
+// float grid -> bytes (x != 0) + "not binary" flag; 4 elements per thread iteration
+template <typename T>
+__global__ __launch_bounds__(256) void binarize_kernel(const T* __restrict__ x, size_t n, uint8_t* __restrict__ occ,
+                                                       int32_t* __restrict__ not_binary) {
+    bool bad = false;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        T v[4];
+        if constexpr (sizeof(T) == 4) {
+            const float4 f = reinterpret_cast<const float4*>(x)[i];
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+            const double2 a = reinterpret_cast<const double2*>(x)[2 * i], b = reinterpret_cast<const double2*>(x)[2 * i + 1];
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        }
+        uint32_t o = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o |= (v[j] != (T)0 ? 1u : 0u) << (8 * j);
+            bad |= !(v[j] == (T)0 || v[j] == (T)1);   // NaN is "bad" too
+        }
+        reinterpret_cast<uint32_t*>(occ)[i] = o;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            occ[i] = x[i] != (T)0;
+            bad |= !(x[i] == (T)0 || x[i] == (T)1);
+        }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(not_binary, 1);
+}
+
+extern "C" int sn_forward_auto(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,
+                               int Y, int G, int kz, int kx, int ky, uint8_t* occ_ws, int32_t* not_binary, void* out,
+                               int out_dtype, sn_stream_t stream) {
+    if (!x || !bank || !lambdas || !occ_ws || !not_binary || !out)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_forward_auto: null pointer");
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_forward_auto: non-positive extent");
+    if (x_dtype != SN_F32 && x_dtype != SN_F64)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_forward_auto: x must be SN_F32 or SN_F64 (byte grids: sn_conv_fused)");
+    if ((uintptr_t)x % 16 || (uintptr_t)occ_ws % 4)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_forward_auto: x must be 16-byte, occ_ws 4-byte aligned");
+    hipStream_t s = sn::as_stream(stream);
+    const size_t n = (size_t)B * Z * X * Y;
+    if (hipMemsetAsync(not_binary, 0, sizeof(int32_t), s) != hipSuccess) return sn::check_launch("sn_forward_auto(memset)");
+    const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
+    if (x_dtype == SN_F32)
+        hipLaunchKernelGGL(binarize_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, n, occ_ws, not_binary);
+    else
+        hipLaunchKernelGGL(binarize_kernel<double>, dim3(blocks), dim3(256), 0, s, (const double*)x, n, occ_ws, not_binary);
+    if (int rc = sn::check_launch("sn_forward_auto(binarize)")) return rc;
+    {   // binary grid: the int8 path on the bytes (through linearity where the shape allows, else the contraction)
+        sn::GateScope gate(not_binary, 0);
+        int rc = sn::conv_fused_lin(occ_ws, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, out, out_dtype, s);
+        if (rc == SN_ERR_UNSUPPORTED) {
+            const size_t ntaps = (size_t)kz * kx * ky;
+            for (int g0 = 0; g0 < G; g0 += 16) {
+                const int gc = (G - g0 < 16) ? G - g0 : 16;
+                const int head = (g0 > 0 ? 1 : 0) | (g0 + gc >= G ? 2 : 0);
+                rc = sn::conv_bank_group(occ_ws, SN_OCC8, bank + g0 * ntaps, lambdas + g0, B, Z, X, Y, gc, G, g0, head, kz,
+                                         kx, ky, nullptr, out, out_dtype, stream);
+                if (rc != SN_OK) break;
+            }
+        }
+        if (rc != SN_OK) return rc;
+    }
+    {   // anything else: the fp32 contraction on x itself
+        sn::GateScope gate(not_binary, 1);
+        const size_t ntaps = (size_t)kz * kx * ky;
+        for (int g0 = 0; g0 < G; g0 += 16) {
+            const int gc = (G - g0 < 16) ? G - g0 : 16;
+            const int head = (g0 > 0 ? 1 : 0) | (g0 + gc >= G ? 2 : 0);
+            const int rc = sn::conv_bank_group(x, x_dtype, bank + g0 * ntaps, lambdas + g0, B, Z, X, Y, gc, G, g0, head, kz,
+                                               kx, ky, nullptr, out, out_dtype, stream);
+            if (rc != SN_OK) return rc;
+        }
+    }
+    return SN_OK;
 }
 
 extern "C" int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,

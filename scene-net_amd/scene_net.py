@@ -317,8 +317,13 @@ class SceneNet(nn.Module):
             bank = self.compute_bank(x.device)
             lam = self.effective_lambdas(x.device)
             out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
-            if self.fused_forward and not return_bank_activations and _hip.conv_fused_supported(x, ks):
-                return _hip.conv_fused(x.contiguous(), bank, lam, out_dtype=out_dtype)
+            if self.fused_forward and not return_bank_activations:
+                if _hip.conv_fused_supported(x, ks):
+                    return _hip.conv_fused(x.contiguous(), bank, lam, out_dtype=out_dtype)
+                if x.dtype in (torch.float32, torch.float64):
+                    # what the reference feeds is f64 {0., 1.} (ToFullDense): a device-side check routes such grids
+                    # to the int8 kernels and anything else to the fp32 contraction, without a host sync
+                    return _hip.forward_auto(x.contiguous(), bank, lam)[0]
             act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
                                       out_dtype=out_dtype)
         return (out, act) if return_bank_activations else out
@@ -339,6 +344,8 @@ class _GeneoForwardFn(torch.autograd.Function):
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
         if fused and not want_act and _hip.conv_fused_supported(x, kernel_size):
             act, out = None, _hip.conv_fused(x, bank, lam, out_dtype=out_dtype)   # forward through linearity
+        elif fused and not want_act and x.dtype in (torch.float32, torch.float64):
+            act, out = None, _hip.forward_auto(x, bank, lam)[0]                    # float grid, usually {0., 1.}
         else:
             act, out = _hip.conv_bank(x, bank, lam, want_act=want_act, want_out=True, out_dtype=out_dtype)
         ctx.save_for_backward(x, out, bank, P, lam, meta["kinds"])

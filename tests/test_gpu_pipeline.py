@@ -38,9 +38,11 @@ def test_scenenet_forward_is_the_reference_forward(hip_device, geneo_num, ks):
     assert (out.cpu() - ref_out).abs().max().item() < TOL
     assert (act.cpu() - ref_act).abs().max().item() < TOL
     assert abs(sum(float(p) for p in model.lambdas_dict.values()) - 1.0) < 1e-6
-    # second call (last lambda was re-created by the first): same answer
+    # second call (last lambda was re-created by the first): same answer.  Without the activations the float grid
+    # goes through sn_forward_auto (binary -> int8 kernels), so "same" is the parity bar, and repeatable bit for bit
     out2 = model(x.to(hip_device))
-    assert torch.equal(out, out2)
+    assert (out - out2).abs().max().item() < 2e-5 and (out2.cpu() - ref_out).abs().max().item() < TOL
+    assert torch.equal(out2, model(x.to(hip_device)))
     # parameters changed in place (an optimiser step) are picked up
     with torch.no_grad():
         model.geneos["cy_0"].geneo_params["radius"].add_(0.75)
@@ -143,3 +145,40 @@ def test_captured_pipeline_replays_on_refilled_buffers(hip_device):
         ref2, refg2 = pipe(other, want_gt=True)
     assert torch.equal(out2, ref2) and torch.equal(grids2.occ, refg2.occ)
     assert not torch.equal(ref2, ref_out)
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_float_occupancy_grids_take_the_int8_path_on_a_device_side_check(hip_device, dt):
+    """The reference feeds f64 {0., 1.} grids (ToFullDense).  sn_forward_auto checks that on the device and gates the
+    int8 and the fp32 launches on the result: same answer either way, no host sync."""
+    from scene_net_amd import _hip
+    torch.manual_seed(3)
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+    occ = torch.rand((2, 1, 24, 20, 32)) < 0.2
+    x = occ.to(dt).to(hip_device)
+    out, flag = _hip.forward_auto(x, bank, lam)
+    assert flag.item() == 0 and out.dtype == dt
+    ref_int8 = _hip.conv_fused(occ.to(hip_device), bank, lam, out_dtype=dt)
+    assert torch.equal(out, ref_int8)                                  # the gated int8 launch produced the output
+    _, ref_fp32 = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True)
+    assert (out - ref_fp32).abs().max().item() < 2e-5
+    # one non-binary element: the flag rises and the fp32 contraction's output comes back, bit for bit
+    x2 = x.clone()
+    x2[1, 0, 3, 4, 5] = 0.5
+    out2, flag2 = _hip.forward_auto(x2, bank, lam)
+    assert flag2.item() == 1
+    assert torch.equal(out2, _hip.conv_bank(x2, bank, lam, want_act=False, want_out=True)[1])
+    x3 = x.clone()
+    x3[0, 0, 0, 0, 0] = float("nan")
+    out3, flag3 = _hip.forward_auto(x3, bank, lam)
+    assert flag3.item() == 1 and torch.isnan(out3[0, 0, 0, 0, 0])
+    # the module routes float grids through it
+    with torch.no_grad():
+        assert torch.equal(model(x), out)
+    # ragged size (numel % 4 != 0, Y % 4 != 0: the int8 kernels do not serve it -> bytes through the fp32 kernel)
+    occ_r = torch.rand((1, 1, 5, 7, 9)) < 0.3
+    xr = occ_r.to(dt).to(hip_device)
+    outr, flagr = _hip.forward_auto(xr, bank, lam)
+    assert flagr.item() == 0
+    assert (outr - _hip.conv_bank(xr, bank, lam, want_act=False, want_out=True)[1]).abs().max().item() < 1e-6
