@@ -238,7 +238,14 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
         const double* src = parts + (size_t)b * nparts * nstat + j;
         double s = 0;
         int q = 0;
-        for (; q + 8 <= nparts; q += 8) {   // eight independent loads in flight, summed in order
+        for (; q + 32 <= nparts; q += 32) {   // 32 independent loads in flight, summed in order
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(q + u) * nstat];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += v[u];
+        }
+        for (; q + 8 <= nparts; q += 8) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(q + u) * nstat];
@@ -262,44 +269,43 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
         for (; b < B; ++b) s += stats[(size_t)b * nstat + threadIdx.x];
         tot[threadIdx.x] = s;
     }
-    // dice, per sample (dice_loss.py:38-41), mean over the batch; gradient coefficients per sample
+    __shared__ double sh_c[kMaxBins], sh_e[kMaxBins], sh_t[2], sh_w[kMaxBins];
+    if (threadIdx.x < kMaxBins) sh_w[threadIdx.x] = threadIdx.x < H ? (double)bin_w[threadIdx.x] : 0.0;
+    // dice, per sample (dice_loss.py:38-41), mean over the batch; gradient coefficients per sample (kept in registers
+    // until the Tversky coefficients are known: every thread then writes its samples' coefficients once)
     double dsum = 0;
-    for (int b = threadIdx.x; b < B; b += kCombineThreads) {
-        double A = 0, C = 0;
+    for (int b = threadIdx.x; b < B; b += kCombineThreads)
         if (cfg.terms & SN_LOSS_DICE) {
             const double* s = stats + (size_t)b * nstat + 2 * H;
-            const double num = s[0] + cfg.dice_smooth, den = s[3] + s[4] + cfg.dice_smooth;
-            dsum += 1.0 - num / den;
-            A = -1.0 / den / B;               // d(1 - num/den)/dp_i = -(t_i den - num 2 p_i)/den^2
-            C = 2.0 * num / (den * den) / B;
+            dsum += 1.0 - (s[0] + cfg.dice_smooth) / (s[3] + s[4] + cfg.dice_smooth);
         }
-        coef[2 * kMaxBins + 3 * b + 0] = A;
-        coef[2 * kMaxBins + 3 * b + 1] = 0.0;
-        coef[2 * kMaxBins + 3 * b + 2] = C;
-    }
     dice_part[threadIdx.x] = dsum;
     __syncthreads();
+    for (int o = kCombineThreads / 2; o > 0; o >>= 1) {   // fixed tree
+        if ((int)threadIdx.x < o) dice_part[threadIdx.x] += dice_part[threadIdx.x + o];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         const double n = (double)B * (double)n_per;
-        double wmse = 0, focal = 0, dice = 0, wbce = 0;
+        double wmse = 0, focal = 0, wbce = 0;
         double mean_w = 0;
-        for (int k = 0; k < H; ++k) mean_w += tot[k] * (double)bin_w[k];
+        for (int k = 0; k < H; ++k) mean_w += tot[k] * sh_w[k];
         mean_w /= n;
         for (int k = 0; k < kMaxBins; ++k) {
-            double c = 0;
-            if (k < H && (cfg.terms & SN_LOSS_WMSE)) {
-                const double wk = (double)bin_w[k] / mean_w;       // w_mse.py:144
-                wmse += wk * tot[H + k];
-                c = 2.0 * cfg.mse_weight * wk / n;                 // d/dp of mean(mse_weight w (t - p)^2)
+            double c = 0, e = 0;
+            if (k < H) {
+                const double wk = sh_w[k] / mean_w;                // w_mse.py:144
+                if (cfg.terms & SN_LOSS_WMSE) {
+                    wmse += wk * tot[H + k];
+                    c = 2.0 * cfg.mse_weight * wk / n;             // d/dp of mean(mse_weight w (t - p)^2)
+                }
+                if (cfg.terms & SN_LOSS_WBCE) {                    // mean(w * bce), dice_loss.py:77-80
+                    wbce += wk * tot[2 * H + 5 + k];
+                    e = wk / n;
+                }
             }
-            coef[k] = c;
-            double e = 0;
-            if (k < H && (cfg.terms & SN_LOSS_WBCE)) {             // mean(w * bce), dice_loss.py:77-80
-                const double wk = (double)bin_w[k] / mean_w;
-                wbce += wk * tot[2 * H + 5 + k];
-                e = wk / n;
-            }
-            coef[kMaxBins + k] = e;
+            sh_c[k] = c;
+            sh_e[k] = e;
         }
         wbce = (cfg.terms & SN_LOSS_WBCE) ? wbce / n : 0.0;
         wmse = (cfg.terms & SN_LOSS_WMSE) ? cfg.mse_weight * wmse / n : 0.0;
@@ -314,19 +320,31 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
             tA = dF * (D - N * (1.0 - a - be)) / (D * D);          // dT/dp_i = (t_i D - N (t_i (1-a-b) + a)) / D^2
             tB = dF * (-N * a) / (D * D);
         }
-        if (cfg.terms & SN_LOSS_DICE) {
-            for (int i = 0; i < kCombineThreads; ++i) dice += dice_part[i];
-            dice /= B;
-        }
-        for (int b = 0; b < B; ++b) {
-            coef[2 * kMaxBins + 3 * b + 0] += tA;
-            coef[2 * kMaxBins + 3 * b + 1] += tB;
-        }
+        sh_t[0] = tA;
+        sh_t[1] = tB;
+        const double dice = (cfg.terms & SN_LOSS_DICE) ? dice_part[0] / B : 0.0;
         loss[0] = wmse + focal + dice + wbce;
-        loss[4] = wbce;
         loss[1] = wmse;
         loss[2] = focal;
         loss[3] = dice;
+        loss[4] = wbce;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxBins) {
+        coef[threadIdx.x] = sh_c[threadIdx.x];
+        coef[kMaxBins + threadIdx.x] = sh_e[threadIdx.x];
+    }
+    for (int b = threadIdx.x; b < B; b += kCombineThreads) {
+        double A = 0, C = 0;
+        if (cfg.terms & SN_LOSS_DICE) {
+            const double* s = stats + (size_t)b * nstat + 2 * H;
+            const double num = s[0] + cfg.dice_smooth, den = s[3] + s[4] + cfg.dice_smooth;
+            A = -1.0 / den / B;               // d(1 - num/den)/dp_i = -(t_i den - num 2 p_i)/den^2
+            C = 2.0 * num / (den * den) / B;
+        }
+        coef[2 * kMaxBins + 3 * b + 0] = A + sh_t[0];
+        coef[2 * kMaxBins + 3 * b + 1] = sh_t[1];
+        coef[2 * kMaxBins + 3 * b + 2] = C;
     }
 }
 
