@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel
     for (int i = tid; i < 2 * s.TXR; i += kThreads) flags[i] = 0u;
     const int nsteps = s.YK >> 2;   // <= 32: tracked one by one, else every step of a non-empty row runs
     const int Y4 = s.Y >> 2;
+    const bool xl_vec4 = (s.py & 3) == 0 && ((s.DR * s.DS) & 3) == 0;   // 16-byte aligned input-tile stores
     if (s.vec)                      // the vector staging only writes columns that hold data: zero the padding once
         for (int i = tid; i < s.DR * s.DS + s.TXR * s.XS; i += kThreads) lds[i] = 0.f;
     // K steps whose window [4 ks, 4 ks + ky + 2] (LDS columns) contains column c
@@ -126,12 +127,15 @@ __global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     if (at[u] < 0) continue;
+                    float dv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float d = g[u][j];
                         if (out) d = (o[u][j] > 0.f) ? d * (1.f - o[u][j] * o[u][j]) : 0.f;
-                        dl[at[u] + j] = d;
+                        dv[j] = d;
                     }
+                    // one 16-byte store per lane (DS % 4 == 0): four ds_write_b32 at stride 4 were 4-way conflicted
+                    *reinterpret_cast<float4*>(dl + at[u]) = make_float4(dv[0], dv[1], dv[2], dv[3]);
                 }
             }
         } else {
@@ -176,11 +180,15 @@ __global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel
                     for (int u = 0; u < 2; ++u) {
                         if (at[u] < 0) continue;
                         unsigned bits = 0u;
+                        if (xl_vec4) {
+                            *reinterpret_cast<float4*>(xl + at[u]) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            xl[at[u] + j] = v[u][j];
-                            if (v[u][j] != 0.f) bits |= steps_of(at[u] - row[u] * s.XS + j);
+                            for (int j = 0; j < 4; ++j) xl[at[u] + j] = v[u][j];
                         }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (v[u][j] != 0.f) bits |= steps_of(at[u] - row[u] * s.XS + j);
                         if (bits) atomicOr(&fl[row[u]], bits);
                     }
                 }
