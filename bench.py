@@ -265,6 +265,8 @@ def main():
     try:
         if args.no_extras:
             raise RuntimeError("skipped (--no-extras)")
+        if world > 1:   # a process group's watchdog thread may touch the device mid-capture: single-process only
+            raise RuntimeError("skipped (world_size > 1)")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
