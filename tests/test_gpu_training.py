@@ -188,3 +188,38 @@ def test_whole_training_step_replays_from_a_hip_graph(hip_device):
     torch.cuda.synchronize()
     for (n, a), (_, b) in zip(eager_model.named_parameters(), graph_model.named_parameters()):
         assert torch.equal(a.detach(), b.detach()), n
+
+
+def test_captured_training_step_api(hip_device):
+    """sna.CapturedTrainingStep: points -> grids (+GT) -> forward -> criterion -> backward -> Adam, one graph; the
+    warm-up steps it runs and its replays equal the same number of eager steps bit for bit."""
+    from scene_net_amd.synthetic import synthetic_tile
+    tiles, labels = zip(*[synthetic_tile(t, 20_000) for t in range(2)])
+
+    def build():
+        torch.manual_seed(21)
+        model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 5, 5)).to(hip_device)
+        with torch.no_grad():
+            for n in model.geneos:
+                model.lambdas_dict[f"lambda_{n}"].mul_(0.1)
+        batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+        pipe = sna.ScenePipeline(model, (32, 32, 32), keep_labels=[15.0])
+        gt = pipe.voxelize(batch, want_gt=True).gt_occ
+        crit = sna.GENEO_Tversky_Loss(targets=gt.float(), weighting_scheme_path=None, save_weighting_scheme=False)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2, capturable=True)
+        return model, batch, pipe, crit, opt
+
+    model, batch, pipe, crit, opt = build()
+    cap = sna.CapturedTrainingStep(pipe, crit, opt, batch, warmup=2)
+    losses = [cap.replay().item() for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    model_e, batch_e, pipe_e, crit_e, opt_e = build()
+    for _ in range(2 + 5):
+        opt_e.zero_grad(set_to_none=True)
+        g = pipe_e.voxelize(batch_e, want_gt=True)
+        loss_e = crit_e(model_e(g.occ), g.gt_occ, model_e.get_cvx_coefficients(), model_e.get_geneo_params())
+        loss_e.backward()
+        opt_e.step()
+    assert loss_e.item() == losses[-1]
+    for (n, a), (_, b) in zip(model_e.named_parameters(), model.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), n
