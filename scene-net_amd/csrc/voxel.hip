@@ -531,24 +531,38 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
     }
     const uint32_t* src = bits_ws + (size_t)b * parts * planes * words;
     const int gtid = blockIdx.x * kThreads + threadIdx.x, gstride = gridDim.x * kThreads;
+    // When a (z,x) row is a power-of-two number of whole words that sit in consecutive lanes (ny = 32, 64, ..., and
+    // words % 64 == 0), the emptiness proof rides on the words this loop has merged anyway; otherwise a second pass
+    // re-merges the words of each row.
+    const int wpr = ny >> 5;   // words per row
+    const bool fused_proof = flags && (ny & 31) == 0 && wpr >= 1 && wpr <= 64 && (wpr & (wpr - 1)) == 0 &&
+                             (words & 63) == 0;
+    bool empty = false;
     for (int w = gtid; w < words; w += gstride) {
-        expand_word<OT>(merged_word(src, parts, planes, words, 0, w), occ + (size_t)b * V + (size_t)w * 32);
+        const uint32_t m0 = merged_word(src, parts, planes, words, 0, w);
+        expand_word<OT>(m0, occ + (size_t)b * V + (size_t)w * 32);
         if (gt_occ) expand_word<OT>(merged_word(src, parts, planes, words, 1, w), gt_occ + (size_t)b * V + (size_t)w * 32);
+        if (fused_proof) {
+            uint32_t any = m0;
+            for (int o = wpr >> 1; o > 0; o >>= 1) any |= __shfl_xor(any, o, 64);
+            empty |= (any == 0u);
+        }
     }
     if (!flags) return;
-    // row r owns bits [r*ny, (r+1)*ny)
-    bool empty = false;
-    for (int r = gtid; r < rows && !empty; r += gstride) {
-        const long lo = (long)r * ny, hi = lo + ny;
-        uint32_t any = 0u;
-        for (long w = lo >> 5; w <= (hi - 1) >> 5; ++w) {
-            uint32_t m = merged_word(src, parts, planes, words, 0, w);
-            const long wlo = w << 5;
-            if (lo > wlo) m &= ~0u << (lo - wlo);
-            if (hi < wlo + 32) m &= ~0u >> (wlo + 32 - hi);
-            any |= m;
+    if (!fused_proof) {
+        // row r owns bits [r*ny, (r+1)*ny)
+        for (int r = gtid; r < rows && !empty; r += gstride) {
+            const long lo = (long)r * ny, hi = lo + ny;
+            uint32_t any = 0u;
+            for (long w = lo >> 5; w <= (hi - 1) >> 5; ++w) {
+                uint32_t m = merged_word(src, parts, planes, words, 0, w);
+                const long wlo = w << 5;
+                if (lo > wlo) m &= ~0u << (lo - wlo);
+                if (hi < wlo + 32) m &= ~0u >> (wlo + 32 - hi);
+                any |= m;
+            }
+            empty = (any == 0u);
         }
-        empty = (any == 0u);
     }
     if (empty) flags[b] = 0;  // benign race: every writer stores 0
 }
