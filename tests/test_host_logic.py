@@ -191,3 +191,42 @@ def test_pointbatch_validation():
         sna.PointBatch.from_tiles([np.zeros((0, 3))], device="cuda:0")
     with pytest.raises(sna.HipLibraryError):
         sna.PointBatch.from_tiles([np.zeros((4, 3))], device="cpu")
+
+
+# ------------------------------------------------------------------ criteria: host-side tables (no GPU needed)
+def test_criterion_weight_tables_match_the_pinned_oracle():
+    """WeightedMSE's per-bin tables (the only host arithmetic of the criteria) against oracle/loss_oracle.py, which is
+    pinned bit-exact to the reference: the in-place frequency replacement chain (w_mse.py:124-126) and the fp32 weights."""
+    import numpy as np
+    from oracle import loss_oracle as lo
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geneo_loss.npz"))
+    for name in [str(c) for c in G["cases"]]:
+        gt = torch.from_numpy(G[f"{name}|gt"])
+        crit = sna.WeightedMSE(targets=gt, weighting_scheme_path=None, save_weighting_scheme=False, weight_alpha=1.5,
+                               weight_epsilon=0.05)
+        assert torch.equal(crit.freqs.cpu(), torch.from_numpy(G[f"{name}|est_freqs"]))
+        crit.freqs = torch.from_numpy(G[f"{name}|freqs"])
+        ranges = torch.from_numpy(G[f"{name}|ranges"])
+        assert torch.equal(crit._bin_values(), lo.bin_value_table(crit.freqs, len(ranges)))
+        assert torch.equal(crit._bin_weights(), lo.bin_weights(crit.freqs, 1.5, 0.05, len(ranges)))
+
+
+def test_criteria_have_no_cpu_path():
+    gt = (torch.rand(2, 1, 4, 4, 4) < 0.2).float()
+    crit = sna.GENEO_Tversky_Loss(targets=gt, weighting_scheme_path=None, save_weighting_scheme=False)
+    with pytest.raises(sna.HipLibraryError):
+        crit(torch.rand(2, 1, 4, 4, 4), gt, {}, {})
+    with pytest.raises(ValueError):
+        sna.WeightedMSE(targets=None, weighting_scheme_path=None)   # the reference builds this error without raising it
+    with pytest.raises(NotImplementedError):
+        sna.BinaryDiceLoss(p=3)
+
+
+def test_scene_net_picks_the_linear_forward_only_for_what_it_serves():
+    from scene_net_amd import _hip
+    assert _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 8), dtype=torch.bool), (9, 9, 9))
+    assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 8)), (9, 9, 9))                       # float grid
+    assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 6), dtype=torch.bool), (9, 9, 9))     # Y % 4
+    assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 8), dtype=torch.bool), (3, 3, 19))    # window > 32 bytes
+    assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 8), dtype=torch.bool), (13, 13, 9))   # table > LDS
+    assert sna.SceneNet.fused_forward is True
