@@ -1,5 +1,5 @@
 /*
- * scenenet_hip.h -- C ABI of the MI355X-native SCENE-Net GENEO forward path.
+ * scenenet_hip.h -- C ABI of the MI355X-native SCENE-Net GENEO hot path (forward, and the training rows of SURVEY 8f).
  *
  * The reference (dlavado/scene-net) is pure Python and has no FFI layer; its
  * "operator API" for this path is a set of Python classes/functions.  Each
@@ -12,7 +12,9 @@
  *   - every pointer is a caller-allocated DEVICE pointer (e.g. tensor.data_ptr())
  *     unless the parameter name ends in `_host`;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
- *     every call only enqueues work on it (no allocation, no sync, graph-capturable);
+ *     every call only enqueues work on it (no allocation, no sync, graph-capturable; the only process state is a
+ *     cache of per-kernel LDS attributes and, with the opt-in "conv_skip_empty_tiles", a device ring of ticket
+ *     counters allocated once);
  *   - return value: 0 = SN_OK, negative = sn_status; sn_last_error() gives the
  *     message of the calling thread's last failure;
  *   - grids are [B, C, Z, X, Y] row-major, y fastest (utils/voxelization.py:193);
