@@ -161,7 +161,7 @@ def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
     py = (ky - 1) // 2
     pya = (py + 3) & ~3
     nsteps = (((kz * kx + 1) // 2 + 1) & ~1) + 1
-    lds = nsteps * 3 * 1024 + 80 + max((((8 + kz - 1) * (16 + kx - 1) + 15) & ~15) * 80, kz * kx * ky * 4)
+    lds = nsteps * 3 * 1024 + 80 + max((((8 + kz - 1) * (16 + kx - 1) + 15) & ~15) * 80, ((kz * kx * ky + 3) & ~3) * 4 + kz * kx * 3 * 17 * 4)
     return (x.dtype == torch.bool and x.dim() == 5 and x.shape[-1] % 4 == 0 and pya - py + 15 + ky - 1 < 32
             and lds <= 160 * 1024)
 

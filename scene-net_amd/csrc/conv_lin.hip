@@ -146,29 +146,55 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         if (tid == 0) misc[0] = (m != m) ? m : ldexpf(1.0f, -F);
     }
     const float twoF = ldexpf(1.0f, F);
+    // Each (kernel row p, digit d) as a zero-padded byte row R[64] with tap dy at byte 32 + dy; a table entry is the
+    // 16-byte window of that row starting at byte 32 + 16 h - m - delta: five aligned dwords and four v_alignbyte
+    // instead of quantising sixteen taps per entry (the table build was ~4 us of the prologue).
+    constexpr int RW = 17;   // dwords per padded row (64 bytes + 1 zero dword for the look-ahead of the funnel shift)
+    uint32_t* rpad = reinterpret_cast<uint32_t*>(kstar + ((ntaps + 3) & ~3));   // [npairs][3][RW]
+    for (int i = tid; i < s.npairs * 3 * RW; i += kThreads) rpad[i] = 0u;
+    __syncthreads();
+    const int ngrp = (s.ky + 3) >> 2;   // dwords that hold taps: bytes 32 .. 32 + ky
+    for (int i = tid; i < s.npairs * ngrp; i += kThreads) {
+        const int p = i / ngrp, gq = i - p * ngrp;
+        uint32_t w0 = 0u, w1 = 0u, w2 = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dy = 4 * gq + j;
+            if (dy < s.ky) {
+                int Q = __float2int_rn(kstar[p * s.ky + dy] * twoF);
+                const int d0 = ((Q + 128) & 255) - 128;
+                Q = (Q - d0) >> 8;
+                const int d1 = ((Q + 128) & 255) - 128;
+                const int d2 = (Q - d1) >> 8;
+                w0 |= (uint32_t)(d0 & 255) << (8 * j);
+                w1 |= (uint32_t)(d1 & 255) << (8 * j);
+                w2 |= (uint32_t)(d2 & 255) << (8 * j);
+            }
+        }
+        rpad[(p * 3 + 0) * RW + 8 + gq] = w0;
+        rpad[(p * 3 + 1) * RW + 8 + gq] = w1;
+        rpad[(p * 3 + 2) * RW + 8 + gq] = w2;
+    }
+    __syncthreads();
     for (int i = tid; i < (s.nsteps + 1) * 64; i += kThreads) {
         const int st = i >> 6, l = i & 63;
         const int m = l & 15, qq = l >> 4;
         const int p = 2 * st + (qq >> 1);
-        uint32_t w[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-        if (p < s.npairs) {
+        const int s0 = 32 + 16 * (qq & 1) - m - (s.PYA - s.py);   // first byte of this lane's window (14 .. 48)
+        const int wq = s0 >> 2, sh = s0 & 3;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int dy = 16 * (qq & 1) + j - m - (s.PYA - s.py);  // halo column y' holds global y0 - PYA + y'
-                if (dy >= 0 && dy < s.ky) {
-                    int Q = __float2int_rn(kstar[p * s.ky + dy] * twoF);
-                    const int d0 = ((Q + 128) & 255) - 128;
-                    Q = (Q - d0) >> 8;
-                    const int d1 = ((Q + 128) & 255) - 128;
-                    const int d2 = (Q - d1) >> 8;
-                    w[0][j >> 2] |= (uint32_t)(d0 & 255) << (8 * (j & 3));
-                    w[1][j >> 2] |= (uint32_t)(d1 & 255) << (8 * (j & 3));
-                    w[2][j >> 2] |= (uint32_t)(d2 & 255) << (8 * (j & 3));
-                }
+        for (int d = 0; d < 3; ++d) {
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+            if (p < s.npairs) {
+                const uint32_t* r = rpad + (p * 3 + d) * RW + wq;
+                uint32_t v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v[j] = r[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_alignbyte(v[j + 1], v[j], sh);
             }
+            At[(st * 3 + d) * 64 + l] = make_uint4(o[0], o[1], o[2], o[3]);
         }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) At[(st * 3 + d) * 64 + l] = make_uint4(w[d][0], w[d][1], w[d][2], w[d][3]);
     }
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
     const float scale = misc[0];
@@ -356,7 +382,8 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     s.rows = (TZ + kz - 1) * s.XP;
     s.NRP = (s.rows + 15) & ~15;
     const size_t halo = (size_t)s.NRP * YB;
-    const size_t kst = (size_t)kz * kx * ky * sizeof(float);
+    // prologue scratch aliasing the halo: K* and the padded digit rows
+    const size_t kst = (((size_t)kz * kx * ky + 3) & ~(size_t)3) * sizeof(float) + (size_t)kz * kx * 3 * 17 * 4;
     const size_t lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (halo > kst ? halo : kst) + 16;
     if (lds > (size_t)kMaxLds) return SN_ERR_UNSUPPORTED;
     int grid = num_cus();
