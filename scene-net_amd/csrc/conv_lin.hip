@@ -123,7 +123,17 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     float mx = 0.0f;
     for (int t = tid; t < ntaps; t += kThreads) {
         float a = 0.0f;
-        for (int g = 0; g < s.G; ++g) a = fmaf(lambdas[g], bank[(size_t)g * ntaps + t], a);
+        for (int g0 = 0; g0 < s.G; g0 += 16) {   // 16 loads in flight, then the fp32 chain in kernel order
+            float w[16], l[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int g = g0 + u < s.G ? g0 + u : s.G - 1;
+                w[u] = bank[(size_t)g * ntaps + t];
+                l[u] = g0 + u < s.G ? lambdas[g] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a = fmaf(l[u], w[u], a);
+        }
         kstar[t] = a;
         const float aa = fabsf(a);
         mx = (aa <= 3.0e38f) ? fmaxf(mx, aa) : __int_as_float(0x7fc00000);  // NaN / inf poisons the kernel
