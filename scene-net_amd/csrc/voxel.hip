@@ -266,18 +266,22 @@ __device__ void derive_desc(const double* __restrict__ box, int nparts, int b, i
     __shared__ double red6[6];
     const double* bb = box + (size_t)b * nparts * 6;
     if (threadIdx.x < 64) {
+        double v[6] = {DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (int pp = threadIdx.x; pp < nparts; pp += 64) {   // a part's six numbers in one go (independent loads)
+            double u[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) u[c] = bb[pp * 6 + c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = (c < 3) ? fmin(v[c], u[c]) : fmax(v[c], u[c]);
+        }
+#pragma unroll
         for (int c = 0; c < 6; ++c) {
-            double v = (c < 3) ? DBL_MAX : -DBL_MAX;
-            for (int pp = threadIdx.x; pp < nparts; pp += 64) {
-                const double u = bb[pp * 6 + c];
-                v = (c < 3) ? fmin(v, u) : fmax(v, u);
-            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                const double u = __shfl_xor(v, o, 64);
-                v = (c < 3) ? fmin(v, u) : fmax(v, u);
+                const double u = __shfl_xor(v[c], o, 64);
+                v[c] = (c < 3) ? fmin(v[c], u) : fmax(v[c], u);
             }
-            if (threadIdx.x == 0) red6[c] = v;
+            if (threadIdx.x == 0) red6[c] = v[c];
         }
     }
     __syncthreads();
