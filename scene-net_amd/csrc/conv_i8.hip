@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     float* bank_s = reinterpret_cast<float*>(xs);  // [G][ntaps]
     {
         const int nb = s.G * ntaps;
-        constexpr int kB = 8;
+        constexpr int kB = 24;   // 16 x 729 floats / 512 threads = 22.8: one batch of loads, one latency
         for (int base = tid; base < nb; base += kThreads * kB) {
             float v[kB];
 #pragma unroll
