@@ -232,6 +232,14 @@ int sn_voxel_occupancy_fused(const double* pts, const double* labels, const int6
 int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets, int B,
                      const double* desc, int nx, int ny, int nz, double fill, void* out, sn_stream_t stream);
 
+/* Grid -> voxel list (vxg_to_xyz, utils/voxelization.py:328-360): EVERY cell of the [n0,n1,n2] grid, in C order
+ * of its indices (np.indices(shape).reshape(3,-1).T), as a row  out[n] = (origin + index * voxel_size, grid[index]),
+ * fp64 like the reference's np.concatenate result.  origin / voxel_size: 3 host doubles each, null = (0,0,0) /
+ * (1,1,1) (the reference defaults).  grid of `dtype` (SN_F32 | SN_F64 | SN_U8 | SN_OCC8); out [n0*n1*n2, 4] f64,
+ * 16-byte aligned.  The product is formed and then added (two roundings, as numpy does). */
+int sn_grid_to_points(const void* grid, int dtype, int n0, int n1, int n2, const double* origin_host,
+                      const double* voxel_size_host, double* out, sn_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Backward (training config; reference: autograd through SceneNet.forward, SCENE_Net.py:322-339, and the
  * generator graphs cylinder.py / arrow.py / neg_sphere.py).  By linearity the whole backward needs ONE

@@ -172,3 +172,15 @@ def hist_on_voxel_groupby(xyz, voxelgrid_dims=(64, 64, 64), voxel_dims=None) -> 
     for i, hist in groups.iterrows():
         data[i] = hist.iloc[0]
     return normalize_xyz(data)
+
+
+def vxg_to_xyz(vxg: np.ndarray, origin=None, voxel_size=None) -> np.ndarray:
+    """utils/voxelization.py:328-360: rows (origin + index * voxel_size, vxg[index]) for EVERY cell, in the C order
+    of np.indices(shape).reshape(3, -1).T; the reference's per-cell Python loop is vxg.reshape(-1).  (V, 4) f64.
+    Pinned against the reference's own output: tests/golden/vxg_to_xyz.npz."""
+    vxg = np.asarray(vxg)
+    origin = np.array([0, 0, 0]) if origin is None else np.asarray(origin)
+    voxel_size = np.array([1, 1, 1]) if voxel_size is None else np.asarray(voxel_size)
+    idx = np.indices(vxg.shape).reshape(3, -1).T
+    points = origin + idx * voxel_size
+    return np.concatenate((points, vxg.reshape(-1, 1)), axis=1).astype(np.float64)

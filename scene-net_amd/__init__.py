@@ -10,7 +10,8 @@ from .geneos import (GENEO_kernel_torch, arrow, cone_kernel, cylinder_kernel, cy
                      negSpherev2)
 from .scene_net import GENEO_Layer, SCENE_Net, SCENE_Net_Class, SCENENetQuantile, SceneNet
 from .transforms import ToFullDense, ToTensor, Voxelization
-from .voxelization import PointBatch, VoxelGrids, hist_on_voxel, prob_to_label, reg_on_voxel, voxelize_batch
+from .voxelization import (PointBatch, VoxelGrids, hist_on_voxel, prob_to_label, reg_on_voxel, voxelize_batch,
+                           vxg_to_xyz)
 from .pipeline import CapturedPipeline, ScenePipeline, shard_range
 from .tiles import TS40KTiles, batch_to_device, pack_csr, point_predictions, split_tile
 from .training import CapturedTrainingStep
@@ -19,7 +20,7 @@ from .criterions import (BinaryDiceLoss, BinaryDiceLoss_BCE, FocalTverskyLoss, G
 
 __all__ = ["SceneNet", "SCENE_Net", "SCENENetQuantile", "SCENE_Net_Class", "cylinder_kernel", "cone_kernel",
            "neg_sphere_kernel", "GENEO_Layer", "GENEO_kernel_torch", "cylinderv2", "arrow", "negSpherev2", "Voxelization",
-           "ToTensor", "ToFullDense", "hist_on_voxel", "reg_on_voxel", "prob_to_label", "voxelize_batch",
+           "ToTensor", "ToFullDense", "hist_on_voxel", "reg_on_voxel", "prob_to_label", "vxg_to_xyz", "voxelize_batch",
            "PointBatch", "VoxelGrids", "ScenePipeline", "CapturedPipeline", "CapturedTrainingStep", "shard_range", "TS40KTiles", "batch_to_device", "pack_csr",
            "point_predictions", "split_tile", "HipLibraryError", "LIB_PATH", "WeightedMSE", "GENEO_Loss",
            "GENEO_Tversky_Loss", "GENEO_Dice_Loss", "GENEO_Dice_BCE", "TverskyLoss", "FocalTverskyLoss", "BinaryDiceLoss",

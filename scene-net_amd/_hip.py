@@ -44,6 +44,7 @@ SYMBOLS = {
                                          _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
+    "sn_grid_to_points": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -361,6 +362,30 @@ def gather_points(grid: torch.Tensor, pts: torch.Tensor, offsets: torch.Tensor, 
                                  _ptr(offsets, torch.int64, "offsets"), B, _ptr(desc, torch.float64, "desc"),
                                  nx, ny, nz, float(fill), _ptr(out), _stream())
     _check(rc, "sn_gather_points")
+    return out
+
+
+def grid_to_points(grid: torch.Tensor, origin=None, voxel_size=None) -> torch.Tensor:
+    """grid [n0,n1,n2] (f32|f64|u8|bool) -> rows [n0*n1*n2, 4] f64 = (origin + index * voxel_size, value), C order of
+    the indices (sn_grid_to_points; utils/voxelization.py:328-360)."""
+    if grid.dim() != 3 or grid.dtype not in _DT:
+        raise HipLibraryError("grid must be [n0,n1,n2] float32/float64/uint8/bool")
+    n0, n1, n2 = grid.shape
+
+    def host3(v, name):
+        if v is None:
+            return None, None
+        a = (ctypes.c_double * 3)(*[float(t) for t in v])
+        if len(v) != 3:
+            raise HipLibraryError(f"{name} must have 3 entries")
+        return a, ctypes.cast(a, ctypes.c_void_p)
+
+    o_keep, o_ptr = host3(origin, "origin")
+    s_keep, s_ptr = host3(voxel_size, "voxel_size")
+    out = torch.empty((n0 * n1 * n2, 4), dtype=torch.float64, device=grid.device)
+    rc = load().sn_grid_to_points(_ptr(grid, None, "grid"), _DT[grid.dtype], n0, n1, n2, o_ptr, s_ptr, _ptr(out),
+                                  _stream())
+    _check(rc, "sn_grid_to_points")
     return out
 
 

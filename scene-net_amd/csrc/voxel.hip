@@ -22,6 +22,8 @@
 //     kernel proves per tile that this cannot be the case (an empty row exists) or raises the tile's
 //     flag, and flagged tiles are redone by the (gated) counting kernels.
 #include "common.h"
+
+#include <type_traits>
 #include <cfloat>
 #include <climits>
 
@@ -47,36 +49,57 @@ __device__ __forceinline__ bool is_kept(double label, const KeepLabels& keep) {
 // ---------------------------------------------------------------- streaming a tile's points
 // Tile b owns points [p0, p1).  A thread-iteration takes TWO points = 48 contiguous bytes as three
 // 16-byte loads; an odd first point is peeled so the pairs start 16-byte aligned.  f(x, y, z, i).
+//
+// A callback that also takes the point's label -- f(x, y, z, i, label) -- gets it loaded next to the coordinates
+// (lab may be null: label 0), instead of fetching labels[i] behind its own branches, one exposed latency per point.
+template <typename F>
+__device__ __forceinline__ void call_point(F&& f, double x, double y, double z, long i, double l) {
+    if constexpr (std::is_invocable_v<F, double, double, double, long, double>) f(x, y, z, i, l);
+    else f(x, y, z, i);
+}
 template <bool kAligned, typename F>
 __device__ __forceinline__ void for_each_point(const double* __restrict__ pts, long p0, long p1, long gtid,
-                                               long gstride, F&& f) {
+                                               long gstride, F&& f, const double* __restrict__ lab = nullptr) {
+    constexpr bool kLab = std::is_invocable_v<F, double, double, double, long, double>;
+    constexpr int kDepth = 2;  // pairs in flight per iteration
+    auto label = [&](long i) { return (kLab && lab) ? lab[i] : 0.0; };
     if (kAligned) {
         long q0 = p0 + (p0 & 1);  // first even point index >= p0
         if (q0 > p1) q0 = p1;
-        if ((p0 & 1) && gtid == 0 && p0 < p1) f(pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2], p0);
+        if ((p0 & 1) && gtid == 0 && p0 < p1)
+            call_point(f, pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2], p0, label(p0));
         const long npair = (p1 - q0) >> 1;
         const double2* src = reinterpret_cast<const double2*>(pts + 3 * q0);
         long i = gtid;
-        for (; i + gstride < npair; i += 2 * gstride) {  // two pairs in flight per iteration
-            const long j = i + gstride;
-            double2 a0 = src[3 * i], a1 = src[3 * i + 1], a2 = src[3 * i + 2];
-            double2 b0 = src[3 * j], b1 = src[3 * j + 1], b2 = src[3 * j + 2];
-            f(a0.x, a0.y, a1.x, q0 + 2 * i);
-            f(a1.y, a2.x, a2.y, q0 + 2 * i + 1);
-            f(b0.x, b0.y, b1.x, q0 + 2 * j);
-            f(b1.y, b2.x, b2.y, q0 + 2 * j + 1);
+        for (; i + (kDepth - 1) * gstride < npair; i += kDepth * gstride) {
+            double2 a[kDepth][3];
+            double l[kDepth][2];
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k) {
+                const long j = i + k * gstride;
+                a[k][0] = src[3 * j]; a[k][1] = src[3 * j + 1]; a[k][2] = src[3 * j + 2];
+                l[k][0] = label(q0 + 2 * j); l[k][1] = label(q0 + 2 * j + 1);
+            }
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k) {
+                const long j = i + k * gstride;
+                call_point(f, a[k][0].x, a[k][0].y, a[k][1].x, q0 + 2 * j, l[k][0]);
+                call_point(f, a[k][1].y, a[k][2].x, a[k][2].y, q0 + 2 * j + 1, l[k][1]);
+            }
         }
-        if (i < npair) {
+        for (; i < npair; i += gstride) {
             double2 a0 = src[3 * i], a1 = src[3 * i + 1], a2 = src[3 * i + 2];
-            f(a0.x, a0.y, a1.x, q0 + 2 * i);
-            f(a1.y, a2.x, a2.y, q0 + 2 * i + 1);
+            const double l0 = label(q0 + 2 * i), l1 = label(q0 + 2 * i + 1);
+            call_point(f, a0.x, a0.y, a1.x, q0 + 2 * i, l0);
+            call_point(f, a1.y, a2.x, a2.y, q0 + 2 * i + 1, l1);
         }
         if (((p1 - q0) & 1) && gtid == 0) {
             const long k = p1 - 1;
-            f(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], k);
+            call_point(f, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], k, label(k));
         }
     } else {
-        for (long i = p0 + gtid; i < p1; i += gstride) f(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], i);
+        for (long i = p0 + gtid; i < p1; i += gstride)
+            call_point(f, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], i, label(i));
     }
 }
 
@@ -320,10 +343,15 @@ __device__ void derive_desc(const double* __restrict__ box, int nparts, int b, i
 }
 
 // ---------------------------------------------------------------- binning
-// largest j with e[j] < p  (== numpy.searchsorted(e, p, side='left') - 1), in [-1, n]
-__device__ __forceinline__ int bin_axis(double p, const double* e, int n, double lo, double inv_step) {
+// largest j with e[j] < p  (== numpy.searchsorted(e, p, side='left') - 1), in [-1, n].  bin_guess is the arithmetic
+// estimate (right except for points sitting on an edge and last-bit rounding), bin_search walks from any start to the
+// exact answer with dependent LDS reads; Binner::flat confirms the three guesses with one round of independent reads
+// and only walks when a guess fails.
+__device__ __forceinline__ int bin_guess(double p, int n, double lo, double inv_step) {
     double f = (p - lo) * inv_step;
-    int k = (f > 0.0) ? (int)fmin(f, (double)n) : 0;
+    return (f > 0.0) ? (int)fmin(f, (double)n) : 0;
+}
+__device__ __forceinline__ int bin_search(double p, const double* e, int n, int k) {
     while (k < n && e[k + 1] < p) ++k;
     while (k >= 0 && !(e[k] < p)) --k;
     return k;
@@ -349,9 +377,21 @@ struct Binner {
     // flat [z][x][y] index, or -1 when the point is NaN / outside the edge table (np.clip to n)
     __device__ __forceinline__ int flat(double x, double y, double z) const {
         if (x != x || y != y || z != z) return -1;
-        int ix = max(bin_axis(x, ex, nx, lo[0], inv[0]), 0);
-        int iy = max(bin_axis(y, ey, ny, lo[1], inv[1]), 0);
-        int iz = max(bin_axis(z, ez, nz, lo[2], inv[2]), 0);
+        int ix = bin_guess(x, nx, lo[0], inv[0]);
+        int iy = bin_guess(y, ny, lo[1], inv[1]);
+        int iz = bin_guess(z, nz, lo[2], inv[2]);
+        // guess k stands iff e[k] < p and not (k < n and e[k+1] < p): exactly where bin_search(k) would stop
+        const double x0 = ex[ix], x1 = ex[min(ix + 1, nx)], y0 = ey[iy], y1 = ey[min(iy + 1, ny)];
+        const double z0 = ez[iz], z1 = ez[min(iz + 1, nz)];
+        const bool okx = (x0 < x) && (ix == nx || !(x1 < x));
+        const bool oky = (y0 < y) && (iy == ny || !(y1 < y));
+        const bool okz = (z0 < z) && (iz == nz || !(z1 < z));
+        if (!(okx && oky && okz)) {
+            ix = bin_search(x, ex, nx, ix);
+            iy = bin_search(y, ey, ny, iy);
+            iz = bin_search(z, ez, nz, iz);
+        }
+        ix = max(ix, 0); iy = max(iy, 0); iz = max(iz, 0);
         if (ix >= nx || iy >= ny || iz >= nz) return -1;
         return (iz * nx + ix) * ny + iy;
     }
@@ -395,12 +435,12 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const double* __restr
     const bool want_tower = (towers != nullptr) && (labels != nullptr);
     int dropped = 0;
     for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kThreads + threadIdx.x,
-                             (long)gridDim.x * kThreads, [&](double x, double y, double z, long i) {
+                             (long)gridDim.x * kThreads, [&](double x, double y, double z, long, double label) {
                                  const int f = bin.flat(x, y, z);
                                  if (f < 0) { ++dropped; return; }
                                  atomicAdd(&c[f], 1);
-                                 if (want_tower && is_kept(labels[i], keep)) atomicAdd(&t[f], 1);
-                             });
+                                 if (want_tower && is_kept(label, keep)) atomicAdd(&t[f], 1);
+                             }, want_tower ? labels : nullptr);
     if (dropped_out && dropped) atomicAdd(&dropped_out[b], dropped);
 }
 
@@ -464,15 +504,15 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
     const bool want_tower = (planes == 2);
     int dropped = 0;
     for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)part * kOccThreads + threadIdx.x,
-                             (long)parts * kOccThreads, [&](double x, double y, double z, long i) {
+                             (long)parts * kOccThreads, [&](double x, double y, double z, long, double label) {
                                  const int f = bin.flat(x, y, z);
                                  if (f < 0) { dropped += (slab == 0); return; }
                                  if (f < f_lo || f >= f_hi) return;
                                  const int g = f - f_lo;
                                  atomicOr(&bits[g >> 5], 1u << (g & 31));
-                                 if (want_tower && is_kept(labels[i], keep))
+                                 if (want_tower && is_kept(label, keep))
                                      atomicOr(&bits[swords + (g >> 5)], 1u << (g & 31));
-                             });
+                             }, want_tower ? labels : nullptr);
     __syncthreads();
     uint32_t* out = bits_ws + ((size_t)b * parts + part) * (size_t)planes * words + (size_t)slab * swords;
     for (int i = threadIdx.x; i < swords; i += kOccThreads) {
@@ -605,12 +645,12 @@ __global__ __launch_bounds__(1024) void occ_fallback_kernel(const double* __rest
     Binner bin;
     bin.init(edges, d, nx, ny, nz);
     for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)threadIdx.x, (long)blockDim.x,
-                             [&](double x, double y, double z, long i) {
+                             [&](double x, double y, double z, long, double label) {
                                  const int f = bin.flat(x, y, z);
                                  if (f < 0) return;
                                  atomicAdd(&c[f], 1);
-                                 if (t && is_kept(labels[i], keep)) atomicAdd(&t[f], 1);
-                             });
+                                 if (t && is_kept(label, keep)) atomicAdd(&t[f], 1);
+                             }, t ? labels : nullptr);
     __threadfence();
     __syncthreads();
     for (size_t i = threadIdx.x; i < V; i += blockDim.x)
@@ -695,6 +735,21 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const int32_t* __res
 // ---------------------------------------------------------------- grid -> points (per-point gather)
 // out[i] = grid[b, vz(i), vx(i), vy(i)] with the SAME binning as the scatter (so a point reads the voxel it fell
 // into); points outside the edge table get `fill`.
+// vxg_to_xyz: one thread per cell, one 32-byte row (two 16-byte stores; a wave writes 2 KB contiguous)
+struct Vec3d { double v[3]; };
+template <typename T>
+__global__ __launch_bounds__(kThreads) void grid_to_points_kernel(const T* __restrict__ grid, int n1, int n2, long V,
+                                                                  Vec3d origin, Vec3d size, double* __restrict__ out) {
+    for (long n = (long)blockIdx.x * kThreads + threadIdx.x; n < V; n += (long)gridDim.x * kThreads) {
+        const long i01 = n / n2;
+        const int i2 = (int)(n - i01 * n2), i1 = (int)(i01 % n1), i0 = (int)(i01 / n1);
+        double2* o = reinterpret_cast<double2*>(out + 4 * n);
+        o[0] = make_double2(__dadd_rn(origin.v[0], __dmul_rn((double)i0, size.v[0])),
+                            __dadd_rn(origin.v[1], __dmul_rn((double)i1, size.v[1])));
+        o[1] = make_double2(__dadd_rn(origin.v[2], __dmul_rn((double)i2, size.v[2])), (double)grid[n]);
+    }
+}
+
 template <typename T, bool kAligned>
 __global__ __launch_bounds__(kThreads) void gather_points_kernel(const T* __restrict__ grid, int channels,
                                                                  const double* __restrict__ pts,
@@ -986,4 +1041,29 @@ extern "C" int sn_gather_points(const void* grid, int dtype, int channels, const
     else { if (al) SN_GATHER(double, true); else SN_GATHER(double, false); }
 #undef SN_GATHER
     return sn::check_launch("sn_gather_points");
+}
+
+extern "C" int sn_grid_to_points(const void* grid, int dtype, int n0, int n1, int n2, const double* origin_host,
+                                 const double* voxel_size_host, double* out, sn_stream_t stream) {
+    if (!grid || !out) return sn::fail(SN_ERR_INVALID_ARG, "sn_grid_to_points: null pointer");
+    if (n0 <= 0 || n1 <= 0 || n2 <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_grid_to_points: empty grid");
+    if (reinterpret_cast<uintptr_t>(out) & 15) return sn::fail(SN_ERR_INVALID_ARG, "sn_grid_to_points: out not 16-byte aligned");
+    Vec3d o{{0.0, 0.0, 0.0}}, sz{{1.0, 1.0, 1.0}};
+    for (int c = 0; c < 3; ++c) {
+        if (origin_host) o.v[c] = origin_host[c];
+        if (voxel_size_host) sz.v[c] = voxel_size_host[c];
+    }
+    const long V = (long)n0 * n1 * n2;
+    hipStream_t s = sn::as_stream(stream);
+    const int blocks = (int)std::min<long>((V + kThreads - 1) / kThreads, 256 * 16);
+#define SN_G2P(T) hipLaunchKernelGGL((grid_to_points_kernel<T>), dim3(blocks), dim3(kThreads), 0, s, (const T*)grid, n1, n2, V, o, sz, out)
+    switch (dtype) {
+        case SN_F32: SN_G2P(float); break;
+        case SN_F64: SN_G2P(double); break;
+        case SN_U8:
+        case SN_OCC8: SN_G2P(uint8_t); break;
+        default: return sn::fail(SN_ERR_INVALID_ARG, "sn_grid_to_points: dtype");
+    }
+#undef SN_G2P
+    return sn::check_launch("sn_grid_to_points");
 }

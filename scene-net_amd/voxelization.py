@@ -168,3 +168,18 @@ def prob_to_label(voxelgrid, tau: float):
     if isinstance(voxelgrid, torch.Tensor):
         return (voxelgrid >= tau).to(voxelgrid.dtype)
     return (voxelgrid >= tau).astype(voxelgrid.dtype)
+
+
+def vxg_to_xyz(vxg, origin=None, voxel_size=None, as_tensor: bool = False):
+    """voxelization.py:328-360: every cell of the voxel grid as a row (origin + index * voxel_size, value) -> (V, 4)
+    f64, rows in C order of the grid's indices.  Returns a numpy array like the reference, or the device tensor with
+    `as_tensor`."""
+    t = vxg if isinstance(vxg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(vxg))
+    if t.dim() != 3:
+        raise ValueError(f"vxg_to_xyz expects a 3-D grid, got shape {tuple(t.shape)}")
+    if not t.is_cuda:
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    if t.dtype not in (torch.float32, torch.float64, torch.uint8, torch.bool):
+        t = t.to(torch.float64)
+    rows = _hip.grid_to_points(t.contiguous(), origin, voxel_size)
+    return rows if as_tensor else rows.cpu().numpy()

@@ -256,6 +256,31 @@ def dump_voxel_normalize():
     print("voxel_normalize.npz:", list(cases))
 
 
+def dump_vxg_to_xyz():
+    """vxg_to_xyz (utils/voxelization.py:328-360): grid -> (V, 4) rows, default and explicit origin / voxel size."""
+    from utils import voxelization as vox
+    rng = np.random.default_rng(33)
+    out = {}
+    cases = {
+        "default_f32": (torch.from_numpy(rng.random((3, 4, 5)).astype(np.float32)), None, None),
+        "binary_f64": (torch.from_numpy((rng.random((4, 2, 6)) < 0.3).astype(np.float64)), None, None),
+        "utm_f64": (torch.from_numpy(rng.random((5, 3, 2))), np.array([5.44e5 + 0.1, 4.634e6 + 0.7, 150.3]),
+                    np.array([0.46875, 0.3, 0.937])),
+        "int_origin": (torch.from_numpy(rng.random((2, 2, 2)).astype(np.float32)), np.array([3, -7, 11]),
+                       np.array([2, 5, 1])),
+    }
+    for k, (g, o, vs) in cases.items():
+        r = vox.vxg_to_xyz(g, origin=o, voxel_size=vs)
+        out[f"{k}/grid"] = g.numpy()
+        if o is not None:
+            out[f"{k}/origin"] = o
+            out[f"{k}/voxel_size"] = vs
+        out[f"{k}/rows"] = np.asarray(r, dtype=np.float64)
+    out["cases"] = np.array(list(cases))
+    np.savez_compressed(os.path.join(OUT, "vxg_to_xyz.npz"), **out)
+    print("vxg_to_xyz.npz:", list(cases))
+
+
 def dump_real_tile_subset():
     """A ~6k-point subset of the reference's data-sample/sample_575.npy (TS40K tile, (N,4) f64 x,y,z,label at
     UTM scale): the six bbox-defining points, every tower (label 15) point and a random remainder."""
@@ -355,8 +380,12 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["loss"]:
         dump_loss()
         sys.exit(0)
+    if sys.argv[1:] == ["vxg"]:
+        dump_vxg_to_xyz()
+        sys.exit(0)
     dump_loss()
     dump_real_tile_subset()
+    dump_vxg_to_xyz()
     dump_voxel_normalize()
     dump_kernels()
     dump_forward()

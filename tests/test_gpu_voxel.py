@@ -191,3 +191,22 @@ def test_separate_bbox_and_desc_entry_points_agree_with_prepare(hip_device):
     assert torch.equal(bbox, bbox2) and torch.equal(desc, desc2)
     for b, t in enumerate(tiles):
         assert np.array_equal(bbox[b].cpu().numpy(), np.concatenate([t.min(0), t.max(0)]))
+
+
+def test_vxg_to_xyz_bit_exact(golden_dir, hip_device):
+    """sn_grid_to_points == the reference's vxg_to_xyz rows (golden) and the oracle at a 64^3 grid, all dtypes."""
+    z = np.load(os.path.join(golden_dir, "vxg_to_xyz.npz"))
+    for k in z["cases"]:
+        o = z[f"{k}/origin"] if f"{k}/origin" in z else None
+        vs = z[f"{k}/voxel_size"] if f"{k}/voxel_size" in z else None
+        got = sna.vxg_to_xyz(torch.from_numpy(z[f"{k}/grid"]), o, vs)
+        assert got.dtype == np.float64 and np.array_equal(got, z[f"{k}/rows"]), k
+    rng = np.random.default_rng(5)
+    origin, size = np.array([5.44e5 + 0.37, 4.634e6 - 0.11, 149.93]), np.array([0.9375, 0.46875, 0.3])
+    for dt in (np.float32, np.float64, np.uint8, np.bool_):
+        r = rng.random((64, 48, 32))
+        g = (r < 0.2).astype(dt) if dt in (np.uint8, np.bool_) else r.astype(dt)
+        got = sna.vxg_to_xyz(torch.from_numpy(g).to(hip_device), origin, size, as_tensor=True)
+        assert got.is_cuda and np.array_equal(got.cpu().numpy(), vo.vxg_to_xyz(g, origin, size)), dt
+    with pytest.raises(ValueError):
+        sna.vxg_to_xyz(np.zeros((4, 4)))

@@ -91,3 +91,13 @@ def test_synthetic_tile_is_deterministic_and_cubic():
 def test_empty_tile_raises():
     with pytest.raises(ValueError):
         vo.voxelgrid_compute(np.zeros((0, 3)), n_xyz=(4, 4, 4))
+
+
+def test_vxg_to_xyz_matches_reference_vectors(golden_dir):
+    """oracle restatement == rows dumped from the reference's vxg_to_xyz (make_golden.py dump_vxg_to_xyz)."""
+    z = np.load(os.path.join(golden_dir, "vxg_to_xyz.npz"))
+    for k in z["cases"]:
+        o = z[f"{k}/origin"] if f"{k}/origin" in z else None
+        vs = z[f"{k}/voxel_size"] if f"{k}/voxel_size" in z else None
+        got = vo.vxg_to_xyz(z[f"{k}/grid"], o, vs)
+        assert got.dtype == np.float64 and np.array_equal(got, z[f"{k}/rows"]), k
