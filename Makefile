@@ -7,7 +7,8 @@ PKG      := scene-net_amd
 SRC      := $(PKG)/csrc
 OUT      := $(PKG)/lib
 OBJDIR   := build/obj
-CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wall -Wno-unused-function
+# EXTRA: e.g. `make -B EXTRA=-DSN_CONV_TIMING` builds the per-workgroup phase clocks tools/conv_timing.py reads
+CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wall -Wno-unused-function $(EXTRA)
 # voxel.hip reproduces numpy's fp64 rounding sequence: never contract a*b+c
 FLAGS_voxel := -ffp-contract=off
 

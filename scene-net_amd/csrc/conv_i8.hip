@@ -180,6 +180,15 @@ __device__ __forceinline__ uint32_t halo_expand(uint8_t* __restrict__ xs, const 
     return seen;
 }
 
+#ifdef SN_CONV_TIMING
+__device__ unsigned long long g_conv_t[1024 * 16];
+__device__ unsigned long long g_conv_w[1024 * 8];
+#define SN_T(k) do { if (threadIdx.x == 0) g_conv_t[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define SN_TACC(k, t0) do { if (threadIdx.x == 0) g_conv_t[blockIdx.x * 16 + (k)] += wall_clock64() - (t0); } while (0)
+#else
+#define SN_T(k) do {} while (0)
+#define SN_TACC(k, t0) do {} while (0)
+#endif
 template <typename OT, int YPB, bool kStage>
 __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __restrict__ x,
                                                                const float* __restrict__ bank,
@@ -191,6 +200,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
+    SN_T(0);
+#ifdef SN_CONV_TIMING
+    if (tid == 0) { g_conv_t[blockIdx.x * 16 + 6] = 0; g_conv_t[blockIdx.x * 16 + 7] = 0; g_conv_t[blockIdx.x * 16 + 8] = 0; g_conv_t[blockIdx.x * 16 + 10] = 0; }
+#endif
 
     const int ZP = s.TZ + s.kz - 1, XP = s.TX + s.kx - 1 + s.XPAD;
     const int rows = ZP * XP;
@@ -227,6 +240,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+    SN_T(1);
     for (int g = wave; g < 16; g += kWaves) {
         float m = 0.0f;
         if (g < s.G)
@@ -250,6 +264,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+    SN_T(2);
     // ---- digit table Wd[s][d][l] (16 bytes: slot (q, p)) and chunk offset table coff[s][q] (4 dwords j)
     const int nchunks = s.R * s.C;
     for (int i = tid; i < KT * 64; i += kThreads) {  // one thread quantises 16 taps once and emits all 3 digit rows
@@ -299,6 +314,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         coff[i] = make_int4(o[0], o[1], o[2], o[3]);
     }
 
+    SN_T(3);
     float lam[4] = {0.f, 0.f, 0.f, 0.f}, sc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -326,8 +342,13 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     }
     __syncthreads();
     if (s.dbg & 16) return;
+    SN_T(4);
 
     while (tile < s.ntiles) {
+#ifdef SN_CONV_TIMING
+        const unsigned long long t_tile = wall_clock64();
+        if (tid == 0) g_conv_t[blockIdx.x * 16 + 8] += 1;
+#endif
         const TileCoord c = tile_coord(s, tile);
         const int next = ticket ? *tnext : tile + (int)gridDim.x;
         const bool has_next = (next < s.ntiles) && !(s.dbg & 2);
@@ -343,7 +364,19 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             for (int w = 0; w < kWaves; ++w) seen |= wseen[w];
             if (!seen) ks_run = 0;
         }
+        // The two waves of a SIMD do not advance evenly -- the older one wins the matrix pipe -- and a wave left alone
+        // on its SIMD runs at about half rate [measured: 1.9x], so issue priority falls with the rounds a wave has
+        // finished: whoever is behind its neighbour catches up.
+        int rounds_done = 0;
         for (int round = wave; round < nrounds; round += kWaves) {
+            if (rounds_done == 0) __builtin_amdgcn_s_setprio(3);
+            else if (rounds_done == 1) __builtin_amdgcn_s_setprio(2);
+            else if (rounds_done == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            ++rounds_done;
+            // last round of the tile: ties go to the older wave, so the younger one leads for the first half
+            const bool lead_half = (round + kWaves >= nrounds) && (wave >= kWaves / 2);
+            if (lead_half) __builtin_amdgcn_s_setprio(1);
             const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
             const uint8_t* xb = xs + lanebase + (lz * XP + lx) * YPB;
 
@@ -398,21 +431,28 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     gather_pair(GC, X, GP);                  \
     mma_pair(W, X, MP);                      \
     __builtin_amdgcn_sched_barrier(0);
-            for (int st = 0; st < ks_run; st += 2) {
-                load_w(st + 1, wb);
-                cb = coff[(st + 1) * 4 + q];
-                SN_SB(ca, 2, wa, 0)
-                SN_SB(ca, 3, wa, 1)
-                SN_SB(cb, 0, wa, 2)
-                SN_SB(cb, 1, wa, 3)
-                const int s2 = (st + 2 < s.KS) ? st + 2 : s.KS - 1;  // look-ahead of the last trip: discarded
-                load_w(s2, wa);
-                ca = coff[s2 * 4 + q];
-                SN_SB(cb, 2, wb, 0)
-                SN_SB(cb, 3, wb, 1)
-                SN_SB(ca, 0, wb, 2)
-                SN_SB(ca, 1, wb, 3)
-            }
+#define SN_TRIP                                                                                   \
+    load_w(st + 1, wb);                                                                           \
+    cb = coff[(st + 1) * 4 + q];                                                                  \
+    SN_SB(ca, 2, wa, 0)                                                                           \
+    SN_SB(ca, 3, wa, 1)                                                                           \
+    SN_SB(cb, 0, wa, 2)                                                                           \
+    SN_SB(cb, 1, wa, 3)                                                                           \
+    const int s2 = (st + 2 < s.KS) ? st + 2 : s.KS - 1; /* look-ahead of the last trip: discarded */ \
+    load_w(s2, wa);                                                                               \
+    ca = coff[s2 * 4 + q];                                                                        \
+    SN_SB(cb, 2, wb, 0)                                                                           \
+    SN_SB(cb, 3, wb, 1)                                                                           \
+    SN_SB(ca, 0, wb, 2)                                                                           \
+    SN_SB(ca, 1, wb, 3)
+            // two loops over one body: the priority changes between them, not behind a branch inside (a join in the
+            // pipelined loop makes the compiler wait for every outstanding LDS read)
+            const int ks_half = (ks_run >> 2) * 2;
+            int st = 0;
+            for (; st < ks_half; st += 2) { SN_TRIP }
+            if (lead_half) __builtin_amdgcn_s_setprio(0);
+            for (; st < ks_run; st += 2) { SN_TRIP }
+#undef SN_TRIP
 #undef SN_SB
 
             // ---- epilogue: recombine the digits, then the same head as the fp32 kernel
@@ -479,8 +519,16 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         // [measured] prefetching the next halo into REGISTERS across the rounds (16 VGPRs) makes hipcc spill (the
         // kernel wants > 400 registers at 2 waves/SIMD) and a 1-wave/SIMD build runs 1.9x slower; LDS-DMA into a
         // staging area (kStage) needs no registers.
+        SN_TACC(10, t_tile);   // wave 0's own rounds
+#ifdef SN_CONV_TIMING
+        if (lane == 0) g_conv_w[blockIdx.x * 8 + wave] += wall_clock64() - t_tile;
+#endif
         if (kStage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
         if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile (and every DMA landed)
+        SN_TACC(6, t_tile);
+#ifdef SN_CONV_TIMING
+        const unsigned long long t_sw = wall_clock64();
+#endif
         if (has_next) {
             const uint32_t seen = kStage ? halo_expand<YPB>(xs, stage, s, tid, rows)
                                          : halo_fill<YPB>(xs, x, s, tile_coord(s, next), tid, XP, rows);
@@ -489,8 +537,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         }
         if (ticket && tid == 0) *tnext = after_next;  // everybody read the old value before the barrier above
         if (!(s.dbg & 4)) __syncthreads();
+        SN_TACC(7, t_sw);
         tile = next;
     }
+    SN_T(5);
 }
 
 size_t lds_bytes(const Shape& s, int ypb, bool stage) {
@@ -627,3 +677,12 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
 }
 
 }  // namespace sn
+
+#ifdef SN_CONV_TIMING
+extern "C" void sn_debug_conv_times(unsigned long long* host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_t), sizeof(unsigned long long) * 1024 * 16);
+    (void)hipMemcpyFromSymbol(host + 1024 * 16, HIP_SYMBOL(g_conv_w), sizeof(unsigned long long) * 1024 * 8);
+    (void)hipMemset((void*)nullptr, 0, 0);
+}
+#endif
