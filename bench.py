@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 code path on a one-GPU box: every rank uses cuda:0, process group over gloo (not a "
+                         "measurement)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the graph-replay and skip-empty extras (profiling runs: keeps per-kernel averages clean)")
     return ap.parse_args()
@@ -114,11 +117,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barrier + max/sum of scalars
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barrier + max/sum of scalars
     n_gpus = world
 
     # ---- model with explicit parameters and this rank's resident batch

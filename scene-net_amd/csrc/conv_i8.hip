@@ -81,6 +81,37 @@ __device__ __forceinline__ TileCoord tile_coord(const Shape& s, int tile) {
 
 __device__ uint32_t g_zero_word[4] = {0u, 0u, 0u, 0u};
 
+// A global load the compiler does not schedule or count (G > 16: later chunks add to the partial sum in `out`).
+// As a plain load hipcc keeps it "possibly in flight" around the round loop and opens every round with
+// s_waitcnt vmcnt(..0), which also waits for the halo DMA issued at the top of the tile.
+__device__ __forceinline__ float load_now(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ double load_now(const double* p) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// The tile ticket, likewise outside the compiler's bookkeeping (and waited for on the spot, by the one thread that
+// draws it): as a plain atomicAdd whose result is used after the rounds, hipcc flushes vmcnt before entering the
+// round loop -- on the dense path too, where no ticket is drawn but the halo DMA is in flight.
+__device__ __forceinline__ int ticket_draw(int* ticket) {
+    int v;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                 : "=v"(v) : "v"(ticket), "v"(1) : "memory");
+    return v;
+}
+
+// workgroup barrier that orders LDS traffic only: global loads (and LDS-DMA) in flight stay in flight
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // slot (step s, lane group q, dword j) -> chunk list index.  The list is c-major (all rows of chunk column
 // 0, then column 1, ...), and the two lane groups that share an LDS cycle (q = 0,1 and q = 2,3) are placed 2
 // (YPB = 96) or 4 (YPB = 80) list entries = halo rows = 16 banks apart.
@@ -145,17 +176,30 @@ __device__ __forceinline__ void halo_dma_issue(uint32_t* __restrict__ stage, con
                                                int rows) {
     constexpr int DW = YPB / 4;
     const int total = rows * DW;
+    // Address arithmetic kept short -- every wave runs this once per tile next to the MFMA rounds: the row split
+    // r -> (zz, xx) by a multiply-high (exact for r < 2^16), 32-bit offsets under one uniform 64-bit sample base.
+    const uint32_t magic = 0xFFFFFFFFu / (uint32_t)XP + 1u;
+    const uint8_t* tb = x + (size_t)c.b * s.Z * s.X * s.Y;
+    const int oz = c.z0 - (s.kz - 1) / 2, ox = c.x0 - (s.kx - 1) / 2, oy = c.y0 - s.PYA;
     for (int base = wave * 64; base < total; base += kThreads) {
         const int idx = base + lane;
         const int r = idx / DW, i = idx - r * DW;
-        const int zz = r / XP, xx = r - zz * XP;
-        const int gz = c.z0 - (s.kz - 1) / 2 + zz, gx = c.x0 - (s.kx - 1) / 2 + xx;
-        const int gy = c.y0 - s.PYA + 4 * i;
-        const bool ok = (idx < total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y);
-        const uint8_t* row = x + (((size_t)c.b * s.Z + gz) * s.X + gx) * s.Y;
-        const void* src = ok ? static_cast<const void*>(row + gy) : static_cast<const void*>(g_zero_word);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + base), 4, 0, 0);
+        const int zz = (int)__umulhi((uint32_t)r, magic), xx = r - zz * XP;
+        const int gz = oz + zz, gx = ox + xx, gy = oy + 4 * i;
+        const bool ok = idx < total && (unsigned)gz < (unsigned)s.Z && (unsigned)gx < (unsigned)s.X &&
+                        (unsigned)gy < (unsigned)s.Y;
+        const void* src = ok ? static_cast<const void*>(tb + ((gz * s.X + gx) * s.Y + gy))
+                             : static_cast<const void*>(g_zero_word);
+        // Inline asm on purpose: hipcc treats the builtin's LDS write as aliasing every later LDS read and puts
+        // s_waitcnt vmcnt(0) in front of the MFMA rounds' first ds_read -- the DMA latency it is meant to hide.
+        // The staging area is only read after the explicit vmcnt(0) + barrier at the end of the tile.  (vmcnt
+        // retires in order, so the compiler's own counted waits, unaware of these loads, can only over-wait.)
+        const uint32_t lds_base =
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(stage + base);
+        uint32_t m0_saved;   // M0 carries the LDS base of the DMA; hand it back as found
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(m0_saved) : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src) : "memory");
     }
 }
 
@@ -233,13 +277,18 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 v[u] = bank[i < nb ? i : 0];
             }
 #pragma unroll
-            for (int u = 0; u < kB; ++u) {
+            for (int u = 0; u < kB; ++u) {   // branch-free: past-the-end items land in the padding slot bank_s[nb]
                 const int i = base + u * kThreads;
-                if (i < nb) bank_s[i] = v[u];
+                bank_s[i < nb ? i : nb] = v[u];
             }
         }
     }
-    __syncthreads();
+    // the first tile's raw rows travel to the staging area (beyond the bank's alias) while the scales and the digit
+    // table are worked out -- issued behind the bank's loads, whose wait would otherwise cover the DMA as well
+    const bool dma_first = kStage && blockIdx.x < (unsigned)s.ntiles &&
+                           (size_t)s.G * ntaps * sizeof(float) <= 4 * (size_t)s.CB;
+    if (dma_first) halo_dma_issue<YPB>(stage, x, s, tile_coord(s, blockIdx.x), wave, lane, XP, rows);
+    lds_barrier();   // not __syncthreads(): its fence would wait for the DMA just issued
     SN_T(1);
     for (int g = wave; g < 16; g += kWaves) {
         float m = 0.0f;
@@ -263,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             scale[g] = (m != m) ? m : ldexpf(1.0f, -F);
         }
     }
-    __syncthreads();
+    lds_barrier();
     SN_T(2);
     // ---- digit table Wd[s][d][l] (16 bytes: slot (q, p)) and chunk offset table coff[s][q] (4 dwords j)
     const int nchunks = s.R * s.C;
@@ -333,10 +382,12 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     // different amounts), dynamic -- one thread draws the ticket of the tile after next while the rounds run.
     int tile = blockIdx.x;
     if (tile >= s.ntiles || (s.dbg & 8)) return;
-    if (ticket && tid == 0) *tnext = gridDim.x + atomicAdd(ticket, 1);
+    if (ticket && tid == 0) *tnext = gridDim.x + ticket_draw(ticket);
+    if (dma_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
     __syncthreads();  // the staged bank (aliasing the halo area) is dead from here on
     {
-        const uint32_t seen = halo_fill<YPB>(xs, x, s, tile_coord(s, tile), tid, XP, rows);
+        const uint32_t seen = dma_first ? halo_expand<YPB>(xs, stage, s, tid, rows)
+                                        : halo_fill<YPB>(xs, x, s, tile_coord(s, tile), tid, XP, rows);
         const bool w = __ballot(seen != 0u) != 0ull;
         if (lane == 0) wseen[wave] = w;
     }
@@ -354,7 +405,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         const bool has_next = (next < s.ntiles) && !(s.dbg & 2);
         if (kStage && has_next) halo_dma_issue<YPB>(stage, x, s, tile_coord(s, next), wave, lane, XP, rows);
         int after_next = 0;
-        if (ticket && tid == 0) after_next = gridDim.x + atomicAdd(ticket, 1);
+        if (ticket && tid == 0) after_next = gridDim.x + ticket_draw(ticket);
         // opt-in (sn_set_option "conv_skip_empty_tiles"): a halo tile without a single set voxel convolves to
         // exactly 0 for every kernel -- its MFMA steps are skipped, the epilogue still writes the (zero) result
         int ks_run = s.KS;
@@ -510,7 +561,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     if (gx < s.X && gy < s.Y) {
                         OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
                         float t = sv;
-                        if (s.head & 1) t += (float)*o;
+                        if (s.head & 1) t += (float)load_now(o);
                         *o = (OT)((s.head & 2) ? relu_nan(tanhf(t)) : t);
                     }
                 }
@@ -547,7 +598,7 @@ size_t lds_bytes(const Shape& s, int ypb, bool stage) {
     const size_t KT = s.KS + kTablePad;
     const size_t rows = (size_t)(s.TZ + s.kz - 1) * (s.TX + s.kx - 1 + s.XPAD);
     const size_t halo = 4 * (size_t)s.CB + (stage ? rows * ypb + 16 : 0);
-    const size_t staged_bank = (size_t)s.G * s.kz * s.kx * s.ky * sizeof(float);  // aliases the halo area
+    const size_t staged_bank = ((size_t)s.G * s.kz * s.kx * s.ky + 1) * sizeof(float);  // aliases the halo area (+ 1 pad)
     return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
 }
 

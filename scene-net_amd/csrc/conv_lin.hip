@@ -62,11 +62,17 @@ struct LinShape {
     int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 16 no deferral
 };
 
+#ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/lin_timing.py
+__device__ unsigned long long g_lin_t[1024 * 16];   // per workgroup: 0 start, 1 tables done, 2 end, 3 tiles, 8.. per wave
+#endif
 template <typename OT>
 __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __restrict__ x,
                                                                const float* __restrict__ bank,
                                                                const float* __restrict__ lambdas, LinShape s,
                                                                OT* __restrict__ out) {
+#ifdef SN_CONV_TIMING
+    if (threadIdx.x == 0) g_lin_t[blockIdx.x * 16 + 0] = wall_clock64();
+#endif
     if (s.gate && *s.gate != s.gate_want) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps + 1][3][64], last step zero
@@ -243,7 +249,15 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         }
     };
 #define SN_EPI2(K) epi_item(std::integral_constant<int, (K)>{}); epi_item(std::integral_constant<int, (K) + 1>{});
+#ifdef SN_CONV_TIMING
+    if (tid == 0) { g_lin_t[blockIdx.x * 16 + 1] = wall_clock64(); g_lin_t[blockIdx.x * 16 + 3] = 0; }
+    if (lane == 0) g_lin_t[blockIdx.x * 16 + 8 + wave] = 0;
+#endif
     for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
+#ifdef SN_CONV_TIMING
+        const unsigned long long t_tile = wall_clock64();
+        if (tid == 0) g_lin_t[blockIdx.x * 16 + 3] += 1;
+#endif
         int b, z0, x0, y0;
         tile_origin(tile, b, z0, x0, y0);
         // ---- halo tile: committed from registers requested during the previous tile's MFMA loop
@@ -349,12 +363,18 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             SN_EPI2(0) SN_EPI2(2) SN_EPI2(4) SN_EPI2(6) SN_EPI2(8) SN_EPI2(10) SN_EPI2(12) SN_EPI2(14)
             pend = false;
         }
+#ifdef SN_CONV_TIMING
+        if (lane == 0) g_lin_t[blockIdx.x * 16 + 8 + wave] += wall_clock64() - t_tile;
+#endif
         __syncthreads();   // every wave is done with the halo before the next tile overwrites it
     }
     if (defer) {   // the last tile's outputs
         SN_EPI2(0) SN_EPI2(2) SN_EPI2(4) SN_EPI2(6) SN_EPI2(8) SN_EPI2(10) SN_EPI2(12) SN_EPI2(14)
     }
 #undef SN_EPI2
+#ifdef SN_CONV_TIMING
+    if (tid == 0) g_lin_t[blockIdx.x * 16 + 2] = wall_clock64();
+#endif
 }
 
 int num_cus() {
@@ -507,3 +527,10 @@ extern "C" int sn_conv_fused(const void* x, int x_dtype, const float* bank, cons
                                             "sn_conv_bank");
     return rc;
 }
+
+#ifdef SN_CONV_TIMING
+extern "C" void sn_debug_lin_times(unsigned long long* host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lin_t), sizeof(unsigned long long) * 1024 * 16);
+}
+#endif
