@@ -97,12 +97,16 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         z0 = (tl % s.nzt) * TZ; tl /= s.nzt;
         b = tl;
     };
+    // Address arithmetic kept short (every thread runs it 16 times per tile, next to the MFMA loop): the row split
+    // r -> (zz, xx) by a multiply-high (exact for r < 2^16), 32-bit offsets under one uniform 64-bit sample base.
+    const uint32_t xp_magic = 0xFFFFFFFFu / (uint32_t)s.XP + 1u;
     auto halo_load = [&](int b, int z0, int x0, int y0, int idx) -> uint32_t {
         const int r = idx / DW, i = idx - r * DW;
-        const int zz = r / s.XP, xx = r - zz * s.XP;
+        const int zz = (int)__umulhi((uint32_t)r, xp_magic), xx = r - zz * s.XP;
         const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
-        if (idx < halo_total && gz >= 0 && gz < s.Z && gx >= 0 && gx < s.X && gy >= 0 && gy < s.Y)
-            return *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((size_t)gz * s.X + gx) * s.Y + gy);
+        if (idx < halo_total && (unsigned)gz < (unsigned)s.Z && (unsigned)gx < (unsigned)s.X &&
+            (unsigned)gy < (unsigned)s.Y)
+            return *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((gz * s.X + gx) * s.Y + gy));
         return 0u;
     };
     auto halo_store = [&](int idx, uint32_t v) {
@@ -125,24 +129,38 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     };
     if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);   // the first tile's halo travels while the tables are built
 
+#ifdef SN_CONV_TIMING
+#define SN_LT(k) do { if (threadIdx.x == 0) g_lin_t[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define SN_LT(k) do {} while (0)
+#endif
+    SN_LT(4);
     // ---- prologue: K* = sum_g lambda_g K_g, its 24-bit fixed point, the Toeplitz digit table
     float mx = 0.0f;
-    for (int t = tid; t < ntaps; t += kThreads) {
-        float a = 0.0f;
-        for (int g0 = 0; g0 < s.G; g0 += 16) {   // 16 loads in flight, then the fp32 chain in kernel order
-            float w[16], l[16];
+    for (int t0 = tid; t0 < ntaps; t0 += 2 * kThreads) {   // two taps per trip: 32 bank loads in flight, one latency
+        const int t1 = t0 + kThreads;
+        const int t1c = t1 < ntaps ? t1 : t0;
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int g0 = 0; g0 < s.G; g0 += 16) {   // then the fp32 chain in kernel order
+            float w0[16], w1[16], l[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int g = g0 + u < s.G ? g0 + u : s.G - 1;
-                w[u] = bank[(size_t)g * ntaps + t];
+                w0[u] = bank[(size_t)g * ntaps + t0];
+                w1[u] = bank[(size_t)g * ntaps + t1c];
                 l[u] = g0 + u < s.G ? lambdas[g] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a = fmaf(l[u], w[u], a);
+            for (int u = 0; u < 16; ++u) {
+                a0 = fmaf(l[u], w0[u], a0);
+                a1 = fmaf(l[u], w1[u], a1);
+            }
         }
-        kstar[t] = a;
-        const float aa = fabsf(a);
-        mx = (aa <= 3.0e38f) ? fmaxf(mx, aa) : __int_as_float(0x7fc00000);  // NaN / inf poisons the kernel
+        kstar[t0] = a0;
+        if (t1 < ntaps) kstar[t1] = a1;
+        const float aa0 = fabsf(a0), aa1 = (t1 < ntaps) ? fabsf(a1) : 0.0f;
+        mx = (aa0 <= 3.0e38f) ? fmaxf(mx, aa0) : __int_as_float(0x7fc00000);  // NaN / inf poisons the kernel
+        mx = (aa1 <= 3.0e38f) ? fmaxf(mx, aa1) : __int_as_float(0x7fc00000);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -152,6 +170,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     float* wmax = misc + 4;  // no static __shared__: the kernel asks for the whole 160 KiB dynamically
     if (lane == 0) wmax[wave] = mx;
     __syncthreads();
+    SN_LT(5);
     int F = 0;
     {
         float m = 0.0f;
@@ -192,6 +211,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         rpad[(p * 3 + 2) * RW + 8 + gq] = w2;
     }
     __syncthreads();
+    SN_LT(6);
     for (int i = tid; i < (s.nsteps + 1) * 64; i += kThreads) {
         const int st = i >> 6, l = i & 63;
         const int m = l & 15, qq = l >> 4;

@@ -86,6 +86,37 @@ def test_points_on_edges_and_degenerate_axes(hip_device):
             _check_tile(g, b, t, None, dims, None)
 
 
+def test_points_one_ulp_around_every_edge(hip_device):
+    """Adversarial for the guess-then-confirm binning: coordinates exactly on every edge of the tile's own linspace
+    table and one ulp to either side, at UTM scale, through the counting path and the occupancy-only (bitmap) path."""
+    rng = np.random.default_rng(77)
+    dims = (64, 64, 64)
+    tiles, labs = [], []
+    for t in range(2):
+        xyz, lab = synthetic_tile(40 + t, 30_000)
+        _, _, g = vo.voxel_counts(xyz, dims, None, lab, [15.0])
+        lo, hi = g["xyzmin"], g["xyzmax"]
+        extra = []
+        for a in range(3):
+            e = g["segments"][a]
+            vals = np.concatenate([e, np.nextafter(e, np.inf), np.nextafter(e, -np.inf)])
+            vals = vals[(vals >= xyz[:, a].min()) & (vals <= xyz[:, a].max())]   # keep the bounding box unchanged
+            pts = lo + rng.random((len(vals), 3)) * (np.minimum(hi, xyz.max(0)) - lo) * 0.999
+            pts = np.clip(pts, xyz.min(0), xyz.max(0))
+            pts[:, a] = vals
+            extra.append(pts)
+        extra = np.concatenate(extra)
+        tiles.append(np.concatenate([xyz, extra]))
+        labs.append(np.concatenate([lab, np.where(rng.random(len(extra)) < 0.3, 15.0, 2.0)]))
+    batch = sna.PointBatch.from_tiles(tiles, labs, device=hip_device)
+    full = sna.voxelize_batch(batch, dims, [15.0], want_density=True, want_gt=True, want_occ=True, want_counts=True)
+    fast = sna.voxelize_batch(batch, dims, [15.0], want_occ=True, want_gt_occ=True)
+    assert fast.counts is None   # the bitmap path
+    for b in range(2):
+        _check_tile(full, b, tiles[b], labs[b], dims, [15.0])
+        _check_tile(fast, b, tiles[b], labs[b], dims, [15.0])
+
+
 def test_density_column_rule(hip_device):
     # a fully occupied y-column has min > 0: its minimum cells normalise to 0 (ToFullDense -> 0)
     rng = np.random.default_rng(2)

@@ -32,6 +32,10 @@ def show(name, a):
 print("workgroups", n, "tiles per wg min/max", t[:, 3].min(), t[:, 3].max())
 show("start", us(t[:, 0] - t0))
 show("prologue (tables)", us(t[:, 1] - t[:, 0]))
+show("  first halo issued", us(t[:, 4] - t[:, 0]))
+show("  K* + max", us(t[:, 5] - t[:, 4]))
+show("  scale, digits rows", us(t[:, 6] - t[:, 5]))
+show("  Toeplitz table", us(t[:, 1] - t[:, 6]))
 show("tile loop + last epilogue", us(t[:, 2] - t[:, 1]))
 show("end", us(t[:, 2] - t0))
 for k in range(8):
