@@ -9,12 +9,34 @@ batch are refilled in place between replays.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, Iterable, Optional
 
 import torch
 
 from .pipeline import ScenePipeline
 from .voxelization import PointBatch
+
+
+def allreduce_flat_grads(params: Iterable[torch.Tensor], group=None, average: bool = True) -> int:
+    """The training exchange of SURVEY 8e: ONE all-reduce per step over the flat vector of the scalar gradients
+    (~50 floats: latency bound over xGMI, so one collective, not one per parameter), written back in place.
+    Every rank must hold gradients for the same parameters.  Returns the number of floats exchanged (0 when there is
+    no process group or it has a single rank).  Equivalent to what DistributedDataParallel's one bucket does for this
+    model; use either."""
+    import torch.distributed as dist
+    ps = [p for p in params if p.grad is not None]
+    if not ps or not (dist.is_available() and dist.is_initialized()):
+        return 0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    grads = [p.grad.reshape(-1) for p in ps]
+    flat = torch.cat(grads)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= world
+    torch._foreach_copy_(grads, list(flat.split([g.numel() for g in grads])))
+    return flat.numel()
 
 
 class CapturedTrainingStep:

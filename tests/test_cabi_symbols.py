@@ -59,6 +59,10 @@ def test_argument_checks_need_no_gpu():
                                   None) == -1  # f64 output not offered
     assert lib.sn_voxel_prepare(p, p, 1, 64, 64, 0, 1, p, None, p, None) == -1
     assert lib.sn_voxel_finalize(p, None, 1, 4, 4, 4, p, None, p, None, None, None) == -1  # gt w/o towers
+    assert lib.sn_grid_to_points(None, 0, 4, 4, 4, None, None, p, None) == -1
+    assert lib.sn_grid_to_points(p, 0, 4, 0, 4, None, None, p, None) == -1   # empty grid
+    assert b"empty" in lib.sn_last_error()
+    assert lib.sn_grid_to_points(p, 0, 4, 4, 4, None, None, ctypes.c_void_p(p.value + 8), None) == -1  # out alignment
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -40,7 +40,14 @@ def _worker(rank, world, port, q):
     ref = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)).to(dev)
     ((ref(x.to(dev)) - y.to(dev)) ** 2).mean().backward()
     ref_grads = {n: float(p.grad) for n, p in ref.named_parameters() if p.grad is not None}
-    q.put((rank, grads, ref_grads))
+    # the same exchange without DDP: one all-reduce over the flat vector of scalar gradients
+    torch.manual_seed(7)
+    own = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)).to(dev)
+    ((own(x[lo:hi].to(dev)) - y[lo:hi].to(dev)) ** 2).mean().backward()
+    n_floats = sna.allreduce_flat_grads(own.parameters())
+    flat_grads = {n: float(p.grad) for n, p in own.named_parameters() if p.grad is not None}
+    assert n_floats == len(flat_grads)
+    q.put((rank, grads, ref_grads, flat_grads))
     dist.destroy_process_group()
 
 
@@ -56,8 +63,9 @@ def test_ddp_gradients_are_the_global_batch_gradients():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, g0, ref0), (_, g1, _) = res
-    assert set(g0) == set(ref0) and len(g0) >= 9
+    (_, g0, ref0, f0), (_, g1, _, f1) = res
+    assert set(g0) == set(ref0) == set(f0) and len(g0) >= 9
     for n in g0:
-        assert g0[n] == g1[n], n  # all-reduced: identical on both ranks
+        assert g0[n] == g1[n] and f0[n] == f1[n], n  # all-reduced: identical on both ranks
         assert abs(float(g0[n]) - float(ref0[n])) <= 1e-5 + 1e-3 * abs(float(ref0[n])), (n, float(g0[n]), float(ref0[n]))
+        assert abs(float(f0[n]) - float(ref0[n])) <= 1e-5 + 1e-3 * abs(float(ref0[n])), (n, float(f0[n]), float(ref0[n]))
