@@ -502,7 +502,23 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             int st = 0;
             for (; st < ks_half; st += 2) { SN_TRIP }
             if (lead_half) __builtin_amdgcn_s_setprio(0);
-            for (; st < ks_run; st += 2) { SN_TRIP }
+            for (; st < ks_run - 2; st += 2) { SN_TRIP }
+            if (st < ks_run) {
+                // the round's last trip, peeled: no look-ahead (nothing follows), and no scheduling fences after its
+                // first half, so the digit recombination of finished accumulator tiles can issue between the last MFMAs
+                load_w(st + 1, wb);
+                cb = coff[(st + 1) * 4 + q];
+                SN_SB(ca, 2, wa, 0)
+                SN_SB(ca, 3, wa, 1)
+                SN_SB(cb, 0, wa, 2)
+                SN_SB(cb, 1, wa, 3)
+                gather_pair(cb, X, 2);
+                mma_pair(wb, X, 0);
+                gather_pair(cb, X, 3);
+                mma_pair(wb, X, 1);
+                mma_pair(wb, X, 2);
+                mma_pair(wb, X, 3);
+            }
 #undef SN_TRIP
 #undef SN_SB
 
