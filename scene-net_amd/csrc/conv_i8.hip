@@ -510,8 +510,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 cb = coff[(st + 1) * 4 + q];
                 SN_SB(ca, 2, wa, 0)
                 SN_SB(ca, 3, wa, 1)
-                SN_SB(cb, 0, wa, 2)
-                SN_SB(cb, 1, wa, 3)
+                gather_pair(cb, X, 0);
+                mma_pair(wa, X, 2);
+                gather_pair(cb, X, 1);
+                mma_pair(wa, X, 3);
                 gather_pair(cb, X, 2);
                 mma_pair(wb, X, 0);
                 gather_pair(cb, X, 3);
