@@ -267,7 +267,7 @@ def main():
                       "conv_launch_ms": e0.elapsed_time(e1) / nf,
                       "max_abs_diff_vs_headline_output": float((out_fused - out).abs().max()),
                       "note": "forward through linearity: one combined 24-bit kernel, Toeplitz implicit GEMM on int8 "
-                              "MFMA (0.48 MFMA/voxel instead of 3); both outputs are within 1e-4 of the fp64 reference"}
+                              "MFMA, kernel rows packed at 24 K-bytes (0.375 MFMA/voxel instead of 3); both outputs are within 1e-4 of the fp64 reference"}
 
     # the same step captured once into a hipGraph and replayed (nothing on the path synchronises or allocates outside
     # torch's allocator, every launch goes to the current stream): removes the ~20 us of dispatch gaps per step.

@@ -11,8 +11,8 @@
 // kernel rows per v_mfma_i32_16x16x64_i8.  The B operand is then 16 CONSECUTIVE, 16-byte aligned halo bytes per
 // lane (one ds_read_b128; no byte-shifted copies), the A operand a precomputed banded Toeplitz table of the three
 // balanced base-256 digits of the 24-bit fixed-point K* (exact int32 accumulation, as in conv_i8.hip).
-// Executed matrix work per output voxel: ceil(kz*kx/2) * 3 MFMAs per 256 outputs = 0.48 MFMA/voxel at 9^3, against
-// 3 MFMA/voxel for the 16-kernel contraction.
+// Executed matrix work per output voxel: ceil(kz*kx/2) * 3 MFMAs per 256 outputs = 0.48 MFMA/voxel at 9^3 -- 0.375 with
+// the rows packed at 24 K-bytes (kW24 below, ky <= 9) -- against 3 MFMA/voxel for the 16-kernel contraction.
 //
 // Bound: MFMA (int8) with LDS well below its limit: per step a wave reads 3 + 4 ds_read_b128 for 12 MFMAs.
 #include "common.h"
@@ -65,7 +65,11 @@ struct LinShape {
 #ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/lin_timing.py
 __device__ unsigned long long g_lin_t[1024 * 16];   // per workgroup: 0 start, 1 tables done, 2 end, 3 tiles, 8.. per wave
 #endif
-template <typename OT>
+// kW24: kernel rows packed at 24 bytes of K instead of 32 (ky <= 9: a 16-y strip's window is 16 + ky - 1 <= 24 bytes), 2.67
+// rows per MFMA step instead of 2: 24 % fewer steps.  K byte kappa = 24 p + o belongs to kernel row p, window byte o; a
+// lane's 16 K bytes are two 8-byte pieces pi = 8 st + 2 q + e (row pi / 3, third pi % 3), so the B operand is two
+// ds_read_b64 (halo offsets from a small LDS table, fetched two steps ahead) and the A table is built per piece.
+template <typename OT, bool kW24>
 __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __restrict__ x,
                                                                const float* __restrict__ bank,
                                                                const float* __restrict__ lambdas, LinShape s,
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps + 1][3][64], last step zero
     float* misc = reinterpret_cast<float*>(At + (size_t)(s.nsteps + 1) * 3 * 64);                // [16]: scale, per-wave maxima
-    uint8_t* halo = reinterpret_cast<uint8_t*>(misc + 16);                      // [NC][NRP] x 16 bytes
+    int* offtab = reinterpret_cast<int*>(misc + 16);                            // kW24: [(nsteps + 3) * 8] piece -> halo offset
+    uint8_t* halo = reinterpret_cast<uint8_t*>(offtab + (kW24 ? (s.nsteps + 3) * 8 : 0));   // [NC][NRP] x 16 bytes
     float* kstar = reinterpret_cast<float*>(halo);                              // [ntaps] (prologue only; aliases halo)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,21 +220,52 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     for (int i = tid; i < (s.nsteps + 1) * 64; i += kThreads) {
         const int st = i >> 6, l = i & 63;
         const int m = l & 15, qq = l >> 4;
-        const int p = 2 * st + (qq >> 1);
-        const int s0 = 32 + 16 * (qq & 1) - m - (s.PYA - s.py);   // first byte of this lane's window (14 .. 48)
-        const int wq = s0 >> 2, sh = s0 & 3;
+        if constexpr (kW24) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            uint32_t o[4] = {0u, 0u, 0u, 0u};
-            if (p < s.npairs) {
-                const uint32_t* r = rpad + (p * 3 + d) * RW + wq;
-                uint32_t v[5];
+            for (int d = 0; d < 3; ++d) {
+                uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int j = 0; j < 5; ++j) v[j] = r[j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_alignbyte(v[j + 1], v[j], sh);
+                for (int e = 0; e < 2; ++e) {   // piece pi: window bytes 8 t .. 8 t + 7 of kernel row p
+                    const int pi = 8 * st + 2 * qq + e;
+                    const int p = pi / 3, t = pi - 3 * p;
+                    if (p < s.npairs) {
+                        const int s0 = 32 + 8 * t - m - (s.PYA - s.py);   // 14 .. 48
+                        const uint32_t* r = rpad + (p * 3 + d) * RW + (s0 >> 2);
+                        const uint32_t v0 = r[0], v1 = r[1], v2 = r[2];
+                        o[2 * e] = __builtin_amdgcn_alignbyte(v1, v0, s0 & 3);
+                        o[2 * e + 1] = __builtin_amdgcn_alignbyte(v2, v1, s0 & 3);
+                    }
+                }
+                At[(st * 3 + d) * 64 + l] = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            At[(st * 3 + d) * 64 + l] = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            const int p = 2 * st + (qq >> 1);
+            const int s0 = 32 + 16 * (qq & 1) - m - (s.PYA - s.py);   // first byte of this lane's window (14 .. 48)
+            const int wq = s0 >> 2, sh = s0 & 3;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                uint32_t o[4] = {0u, 0u, 0u, 0u};
+                if (p < s.npairs) {
+                    const uint32_t* r = rpad + (p * 3 + d) * RW + wq;
+                    uint32_t v[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) v[j] = r[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_alignbyte(v[j + 1], v[j], sh);
+                }
+                At[(st * 3 + d) * 64 + l] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if constexpr (kW24) {   // piece -> halo byte offset (row (dz, dx), chunk t >> 1, half t & 1); past the end: 0
+        for (int pi = tid; pi < (s.nsteps + 3) * 8; pi += kThreads) {
+            const int p = pi / 3, t = pi - 3 * p;
+            int off = 0;
+            if (p < s.npairs) {
+                const int dz = p / s.kx, dx = p - dz * s.kx;
+                off = ((t >> 1) * s.NRP + dz * s.XP + dx) * 16 + 8 * (t & 1);
+            }
+            offtab[pi] = off;
         }
     }
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
@@ -270,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     };
 #define SN_EPI2(K) epi_item(std::integral_constant<int, (K)>{}); epi_item(std::integral_constant<int, (K) + 1>{});
 #ifdef SN_CONV_TIMING
-    if (tid == 0) { g_lin_t[blockIdx.x * 16 + 1] = wall_clock64(); g_lin_t[blockIdx.x * 16 + 3] = 0; }
+    if (tid == 0) { g_lin_t[blockIdx.x * 16 + 1] = wall_clock64(); g_lin_t[blockIdx.x * 16 + 3] = 0; g_lin_t[blockIdx.x * 16 + 7] = 0; }
     if (lane == 0) g_lin_t[blockIdx.x * 16 + 8 + wave] = 0;
 #endif
     for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
@@ -283,6 +319,9 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         // ---- halo tile: committed from registers requested during the previous tile's MFMA loop
         halo_commit();
         __syncthreads();
+#ifdef SN_CONV_TIMING
+        if (tid == 0) g_lin_t[blockIdx.x * 16 + 7] += wall_clock64() - t_tile;   // commit + barrier
+#endif
         if (tile + (int)gridDim.x < s.ntiles) halo_issue(tile + gridDim.x);   // lands while the MFMAs below run
 
         // ---- this wave's z plane: 4 strips x 3 digit planes of 16 y x 16 rows
@@ -322,6 +361,24 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             for (int v = 0; v < 4; ++v) xv[v] = *reinterpret_cast<const uint4*>(bp + v * cstride);
             advance();
         };
+        int2 offA = make_int2(0, 0), offB = make_int2(0, 0);   // kW24: halo offsets of this lane's two pieces
+        if constexpr (kW24) {
+            offA = *reinterpret_cast<const int2*>(offtab + 2 * q);
+            offB = *reinterpret_cast<const int2*>(offtab + 8 + 2 * q);
+        }
+        auto load_step24 = [&](int st, uint4 (&a)[3], uint4 (&xv)[4], int2& off) {
+            const uint8_t* b0 = hb + off.x;
+            const uint8_t* b1 = hb + off.y;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a[d] = At[(st * 3 + d) * 64 + lane];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(b0 + v * cstride);
+                const uint2 hi = *reinterpret_cast<const uint2*>(b1 + v * cstride);
+                xv[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+            off = *reinterpret_cast<const int2*>(offtab + 8 * (st + 2) + 2 * q);   // for this set's next use
+        };
         auto mma_step = [&](const uint4 (&a)[3], const uint4 (&xv)[4]) {
 #pragma unroll
             for (int v = 0; v < 4; ++v)
@@ -332,19 +389,25 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         };
         // the table holds an even number of steps plus one all-zero step, so the loop body is branch-free: a join
         // between "prefetched" and "did not prefetch" paths would make hipcc wait for the NEW loads (lgkmcnt(3))
-        load_step(0, aA, xA);
+        if constexpr (kW24) load_step24(0, aA, xA, offA);
+        else load_step(0, aA, xA);
         __builtin_amdgcn_sched_barrier(0);
         // per step: the 7 LDS requests of the next step are spread between this step's 12 MFMAs (2 MFMAs, 1 read, ...)
 #define SN_LIN_G(NR)                                                                                               \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                            \
     __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-#define SN_LIN_INTERLEAVE() SN_LIN_G(2) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1)
+#define SN_LIN_INTERLEAVE()                                                                                        \
+    if constexpr (kW24) { SN_LIN_G(2) SN_LIN_G(2) SN_LIN_G(2) SN_LIN_G(2) SN_LIN_G(2) SN_LIN_G(2) }   /* 12 reads */     \
+    else { SN_LIN_G(2) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) SN_LIN_G(1) }                  /* 7 reads */
+#define SN_LIN_LOAD(ST, A, X, OFF)                                                                                 \
+    if constexpr (kW24) load_step24((ST), A, X, OFF);                                                             \
+    else load_step((ST), A, X);
 #define SN_LIN_PAIR(ST)                                                                                            \
-    load_step((ST) + 1, aB, xB);                                                                                  \
+    SN_LIN_LOAD((ST) + 1, aB, xB, offB)                                                                           \
     mma_step(aA, xA);                                                                                             \
     SN_LIN_INTERLEAVE()                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
-    load_step((ST) + 2, aA, xA);                                                                                  \
+    SN_LIN_LOAD((ST) + 2, aA, xA, offA)                                                                           \
     mma_step(aB, xB);                                                                                             \
     SN_LIN_INTERLEAVE()                                                                                           \
     __builtin_amdgcn_sched_barrier(0);
@@ -364,6 +427,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             SN_LIN_PAIR(st)
         }
 #undef SN_LIN_PAIR
+#undef SN_LIN_LOAD
 #undef SN_LIN_INTERLEAVE
 #undef SN_LIN_G
         // ---- epilogue: D[m = 4 q + i][n]: lane holds 4 consecutive y of row x0 + n
@@ -427,21 +491,26 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     if (nt > 0x7fffffff) return SN_ERR_UNSUPPORTED;
     s.ntiles = (int)nt;
     s.npairs = kz * kx;
-    s.nsteps = ((s.npairs + 1) / 2 + 1) & ~1;   // even (branch-free two-set software pipeline)
+    // 24-byte packing of the kernel rows when a strip's window fits 24 halo bytes (ky <= 9 with PYA == py)
+    const char* no24 = getenv("SN_CONV_LIN_NO24");
+    const bool w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !(no24 && no24[0] == '1');
+    s.nsteps = w24 ? (((3 * s.npairs + 7) / 8 + 1) & ~1)
+                   : (((s.npairs + 1) / 2 + 1) & ~1);   // even (branch-free two-set software pipeline)
     s.XP = TX + kx - 1;
     s.rows = (TZ + kz - 1) * s.XP;
     s.NRP = (s.rows + 15) & ~15;
     const size_t halo = (size_t)s.NRP * YB;
     // prologue scratch aliasing the halo: K* and the padded digit rows
     const size_t kst = (((size_t)kz * kx * ky + 3) & ~(size_t)3) * sizeof(float) + (size_t)kz * kx * 3 * 17 * 4;
-    const size_t lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (halo > kst ? halo : kst) + 16;
+    const size_t lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (w24 ? (size_t)(s.nsteps + 3) * 8 * 4 : 0) +
+                       (halo > kst ? halo : kst) + 16;
     if (lds > (size_t)kMaxLds) return SN_ERR_UNSUPPORTED;
     int grid = num_cus();
     if (grid > s.ntiles) grid = s.ntiles;
     s.dbg = getenv("SN_CONV_LIN_DBG") ? atoi(getenv("SN_CONV_LIN_DBG")) : 0;
 #define SN_LAUNCH_LIN(OT)                                                                                         \
     do {                                                                                                          \
-        auto kern = conv_lin_i8_kernel<OT>;                                                                       \
+        auto kern = w24 ? conv_lin_i8_kernel<OT, true> : conv_lin_i8_kernel<OT, false>;                           \
         if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                     \
             return sn::check_launch("sn_conv_fused(hipFuncSetAttribute)");                                        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (OT*)out);         \

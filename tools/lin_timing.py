@@ -37,6 +37,7 @@ show("  K* + max", us(t[:, 5] - t[:, 4]))
 show("  scale, digits rows", us(t[:, 6] - t[:, 5]))
 show("  Toeplitz table", us(t[:, 1] - t[:, 6]))
 show("tile loop + last epilogue", us(t[:, 2] - t[:, 1]))
+show("  halo commit + barrier (sum)", us(t[:, 7]))
 show("end", us(t[:, 2] - t0))
 for k in range(8):
     show(f"wave {k} busy (sum)", us(t[:, 8 + k]))
