@@ -364,6 +364,22 @@ def test_fused_linear_against_oracle_and_dense_kernel(hip_device, shape, ks, G):
     assert torch.equal(out, _hip.conv_fused(x, bank.to(hip_device).contiguous(), lam.to(hip_device)))  # deterministic
 
 
+@pytest.mark.parametrize("shape,ks", [((2, 1, 24, 40, 64), (9, 9, 9)), ((1, 1, 16, 20, 72), (5, 3, 7)),
+                                      ((3, 1, 9, 17, 128), (9, 5, 5)), ((1, 1, 8, 16, 64), (3, 9, 2))])
+def test_fused_linear_row_packings_are_bit_identical(hip_device, monkeypatch, shape, ks):
+    """The 24-byte packing of the kernel rows (ky <= 9) and the 32-byte one accumulate the same integers."""
+    torch.manual_seed(11)
+    G = 5
+    x = (torch.rand(shape) < 0.2).to(hip_device)
+    bank = (_rand_bank(G, ks, 3, "cpu") * torch.logspace(-1, 0.3, G).view(G, 1, 1, 1)).to(hip_device).contiguous()
+    lam = ((torch.rand(G) - 0.4) / G).to(hip_device)
+    packed = _hip.conv_fused(x, bank, lam)
+    monkeypatch.setenv("SN_CONV_LIN_NO24", "1")
+    wide = _hip.conv_fused(x, bank, lam)
+    monkeypatch.delenv("SN_CONV_LIN_NO24")
+    assert torch.equal(packed, wide)
+
+
 def test_fused_linear_rejects_what_it_does_not_serve(hip_device):
     bank = _rand_bank(2, (3, 3, 3), 1, hip_device).contiguous()
     lam = torch.tensor([0.5, 0.5], device=hip_device)
