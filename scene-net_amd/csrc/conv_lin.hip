@@ -132,7 +132,6 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         for (int base = tid + kHaloRegs * kThreads; base < halo_total; base += kThreads)   // halos beyond the registers
             halo_store(base, halo_load(hb_b, hb_z0, hb_x0, hb_y0, base));
     };
-    if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);   // the first tile's halo travels while the tables are built
 
 #ifdef SN_CONV_TIMING
 #define SN_LT(k) do { if (threadIdx.x == 0) g_lin_t[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
@@ -142,19 +141,27 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     SN_LT(4);
     // ---- prologue: K* = sum_g lambda_g K_g, its 24-bit fixed point, the Toeplitz digit table
     float mx = 0.0f;
-    for (int t0 = tid; t0 < ntaps; t0 += 2 * kThreads) {   // two taps per trip: 32 bank loads in flight, one latency
+    float w0[16], w1[16], l[16];
+    auto kload = [&](int t0, int g0) {   // two taps x 16 kernels: 32 bank loads (+ the lambdas) in flight, one latency
         const int t1 = t0 + kThreads;
-        const int t1c = t1 < ntaps ? t1 : t0;
-        float a0 = 0.0f, a1 = 0.0f;
-        for (int g0 = 0; g0 < s.G; g0 += 16) {   // then the fp32 chain in kernel order
-            float w0[16], w1[16], l[16];
+        const int t0c = t0 < ntaps ? t0 : 0, t1c = t1 < ntaps ? t1 : t0c;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int g = g0 + u < s.G ? g0 + u : s.G - 1;
-                w0[u] = bank[(size_t)g * ntaps + t0];
-                w1[u] = bank[(size_t)g * ntaps + t1c];
-                l[u] = g0 + u < s.G ? lambdas[g] : 0.0f;
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int g = g0 + u < s.G ? g0 + u : s.G - 1;
+            w0[u] = bank[(size_t)g * ntaps + t0c];
+            w1[u] = bank[(size_t)g * ntaps + t1c];
+            l[u] = g0 + u < s.G ? lambdas[g] : 0.0f;
+        }
+    };
+    // the first batch of bank loads is requested BEFORE the first tile's halo (16 loads per thread behind ~2 us of
+    // address arithmetic), so that its latency passes meanwhile; the halo then travels while the tables are built
+    kload(tid, 0);
+    if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);
+    for (int t0 = tid; t0 < ntaps; t0 += 2 * kThreads) {
+        const int t1 = t0 + kThreads;
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int g0 = 0; g0 < s.G; g0 += 16) {   // the fp32 chain in kernel order
+            if (t0 != tid || g0 != 0) kload(t0, g0);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 a0 = fmaf(l[u], w0[u], a0);
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         const uint8_t* hb = halo + (lz * s.XP + n) * 16;
         // software pipeline, two register sets: the operands of step st + 1 are requested before the 12 MFMAs of
         // step st issue; the halo offset of a step comes from registers (dz, dx advance by two kernel rows per step)
-        const int nst = (s.dbg & 2) ? 0 : s.nsteps;   // even
+        const int nst = (s.dbg & 2) ? 0 : s.nsteps;   // pairs of steps, then a lone one if odd
         int pdz = 0, pdx = (q >> 1);                 // kernel row p = 2 st + (q >> 1) of this lane group
         if (pdx >= s.kx) { pdx -= s.kx; ++pdz; }   // kx == 1
         const int hoff = (q & 1) * s.NRP * 16;   // the window's second chunk is one chunk plane further
@@ -423,9 +430,10 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             SN_LIN_PAIR(14) SN_EPI2(14)
             st0 = 16;
         }
-        for (int st = st0; st < nst; st += 2) {
+        for (int st = st0; st + 1 < nst; st += 2) {
             SN_LIN_PAIR(st)
         }
+        if (nst & 1) mma_step(aA, xA);   // odd step count: the last step was loaded by the last pair (block-uniform)
 #undef SN_LIN_PAIR
 #undef SN_LIN_LOAD
 #undef SN_LIN_INTERLEAVE
@@ -494,8 +502,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     // 24-byte packing of the kernel rows when a strip's window fits 24 halo bytes (ky <= 9 with PYA == py)
     const char* no24 = getenv("SN_CONV_LIN_NO24");
     const bool w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !(no24 && no24[0] == '1');
-    s.nsteps = w24 ? (((3 * s.npairs + 7) / 8 + 1) & ~1)
-                   : (((s.npairs + 1) / 2 + 1) & ~1);   // even (branch-free two-set software pipeline)
+    s.nsteps = w24 ? (3 * s.npairs + 7) / 8 : (s.npairs + 1) / 2;   // odd counts end with a lone step after the pairs
     s.XP = TX + kx - 1;
     s.rows = (TZ + kz - 1) * s.XP;
     s.NRP = (s.rows + 15) & ~15;
