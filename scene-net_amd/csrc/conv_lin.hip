@@ -153,15 +153,14 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             l[u] = g0 + u < s.G ? lambdas[g] : 0.0f;
         }
     };
-    // the first batch of bank loads is requested BEFORE the first tile's halo (16 loads per thread behind ~2 us of
-    // address arithmetic), so that its latency passes meanwhile; the halo then travels while the tables are built
-    kload(tid, 0);
+    // the first tile's halo is requested first and travels while the tables are built ([measured] the bank loads ahead
+    // of it instead: the prologue got 0.6 us longer -- the halo's 16 loads then queue behind 48 others)
     if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);
     for (int t0 = tid; t0 < ntaps; t0 += 2 * kThreads) {
         const int t1 = t0 + kThreads;
         float a0 = 0.0f, a1 = 0.0f;
         for (int g0 = 0; g0 < s.G; g0 += 16) {   // the fp32 chain in kernel order
-            if (t0 != tid || g0 != 0) kload(t0, g0);
+            kload(t0, g0);
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 a0 = fmaf(l[u], w0[u], a0);
