@@ -112,7 +112,15 @@ def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: s
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """HIP stream handle of torch's current stream on the current device (what every launch of the C ABI goes to).
+    The raw accessor costs ~0.3 us; torch.cuda.current_stream() builds a Stream object (~12 us per call measured on
+    the GPU box, six calls per step: the fused forward step is 0.11 ms of GPU work)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
