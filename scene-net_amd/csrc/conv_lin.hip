@@ -94,7 +94,6 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     // (kHaloRegs per thread; larger halos take a synchronous remainder pass)
     constexpr int DW = YB / 4;
     constexpr int kHaloRegs = 16;
-    const int halo_total = s.rows * DW;
     uint32_t hreg[kHaloRegs];
     auto tile_origin = [&](int tl, int& b, int& z0, int& x0, int& y0) {
         y0 = (tl % s.nyt) * TY; tl /= s.nyt;
@@ -102,35 +101,52 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         z0 = (tl % s.nzt) * TZ; tl /= s.nzt;
         b = tl;
     };
-    // Address arithmetic kept short (every thread runs it 16 times per tile, next to the MFMA loop): the row split
-    // r -> (zz, xx) by a multiply-high (exact for r < 2^16), 32-bit offsets under one uniform 64-bit sample base.
-    const uint32_t xp_magic = 0xFFFFFFFFu / (uint32_t)s.XP + 1u;
-    auto halo_load = [&](int b, int z0, int x0, int y0, int idx) -> uint32_t {
-        const int r = idx / DW, i = idx - r * DW;
-        const int zz = (int)__umulhi((uint32_t)r, xp_magic), xx = r - zz * s.XP;
-        const int gz = z0 - s.pz + zz, gx = x0 - s.px + xx, gy = y0 - s.PYA + 4 * i;
-        if (idx < halo_total && (unsigned)gz < (unsigned)s.Z && (unsigned)gx < (unsigned)s.X &&
-            (unsigned)gy < (unsigned)s.Y)
-            return *reinterpret_cast<const uint32_t*>(x + (size_t)b * V + ((gz * s.X + gx) * s.Y + gy));
-        return 0u;
-    };
-    auto halo_store = [&](int idx, uint32_t v) {
-        if (idx < halo_total) {
-            const int r = idx / DW, i = idx - r * DW;
-            reinterpret_cast<uint32_t*>(halo)[((i >> 2) * s.NRP + r) * 4 + (i & 3)] = v;
+    // Thread -> (dword column i, first halo row): kThreads / DW = 25 rows per pass (the last 12 threads idle), so a
+    // pass advances every thread by the same (dz, dx) and the row split r -> (zz, xx) is incremental -- one add and
+    // one wrap per load instead of divisions (every thread runs this 16 times per tile, next to the MFMA loop).
+    constexpr int RPP = kThreads / DW;
+    const int h_i = tid % DW, h_r0 = tid / DW;
+    const bool h_thread = tid < RPP * DW;
+    const int h_zz0 = h_r0 / s.XP, h_xx0 = h_r0 - h_zz0 * s.XP;
+    const int h_dzz = RPP / s.XP, h_dxx = RPP - h_dzz * s.XP;
+    const int h_lds0 = ((h_i >> 2) * s.NRP + h_r0) * 4 + (h_i & 3);   // dword index of (row h_r0, column i) in the halo
+    int hb_b = 0, hb_z0 = 0, hb_x0 = 0, hb_y0 = 0;   // tile the registers belong to
+    // passes [u0, u1) of the tile (hb_*): f(u, value)
+    auto halo_rows = [&](int u0, int u1, auto&& f) {
+        const uint8_t* xb = x + (size_t)hb_b * V;
+        const int gy = hb_y0 - s.PYA + 4 * h_i;
+        const bool oky = h_thread && (unsigned)gy < (unsigned)s.Y;
+        int zz = h_zz0, xx = h_xx0, r = h_r0;
+        for (int u = 0; u < u0; ++u) {   // (u0 > 0 only for halos beyond the registers)
+            r += RPP; zz += h_dzz; xx += h_dxx;
+            if (xx >= s.XP) { xx -= s.XP; ++zz; }
+        }
+#pragma unroll
+        for (int u = u0; u < u1; ++u) {
+            const int gz = hb_z0 - s.pz + zz, gx = hb_x0 - s.px + xx;
+            uint32_t v = 0u;
+            if (oky && r < s.rows && (unsigned)gz < (unsigned)s.Z && (unsigned)gx < (unsigned)s.X)
+                v = *reinterpret_cast<const uint32_t*>(xb + ((gz * s.X + gx) * s.Y + gy));
+            f(u, v);
+            r += RPP; zz += h_dzz; xx += h_dxx;
+            const bool w = xx >= s.XP;
+            xx -= w ? s.XP : 0;
+            zz += w;
         }
     };
-    int hb_b = 0, hb_z0 = 0, hb_x0 = 0, hb_y0 = 0;   // tile the registers belong to
+    auto halo_store = [&](int u, uint32_t v) {
+        if (h_thread && h_r0 + u * RPP < s.rows) reinterpret_cast<uint32_t*>(halo)[h_lds0 + u * RPP * 4] = v;
+    };
     auto halo_issue = [&](int tl) {
         tile_origin(tl, hb_b, hb_z0, hb_x0, hb_y0);
-#pragma unroll
-        for (int u = 0; u < kHaloRegs; ++u) hreg[u] = halo_load(hb_b, hb_z0, hb_x0, hb_y0, tid + u * kThreads);
+        halo_rows(0, kHaloRegs, [&](int u, uint32_t v) { hreg[u] = v; });
     };
+    const int h_passes = (s.rows + RPP - 1) / RPP;
     auto halo_commit = [&]() {
 #pragma unroll
-        for (int u = 0; u < kHaloRegs; ++u) halo_store(tid + u * kThreads, hreg[u]);
-        for (int base = tid + kHaloRegs * kThreads; base < halo_total; base += kThreads)   // halos beyond the registers
-            halo_store(base, halo_load(hb_b, hb_z0, hb_x0, hb_y0, base));
+        for (int u = 0; u < kHaloRegs; ++u) halo_store(u, hreg[u]);
+        for (int u = kHaloRegs; u < h_passes; ++u)   // halos beyond the registers: synchronous
+            halo_rows(u, u + 1, [&](int uu, uint32_t v) { halo_store(uu, v); });
     };
 
 #ifdef SN_CONV_TIMING
