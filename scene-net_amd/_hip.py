@@ -169,8 +169,14 @@ def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
     kz, kx, ky = (int(k) for k in kernel_size)
     py = (ky - 1) // 2
     pya = (py + 3) & ~3
-    nsteps = (((kz * kx + 1) // 2 + 1) & ~1) + 1
-    lds = nsteps * 3 * 1024 + 80 + max((((8 + kz - 1) * (16 + kx - 1) + 15) & ~15) * 80, ((kz * kx * ky + 3) & ~3) * 4 + kz * kx * 3 * 17 * 4)
+    # mirrors sn::conv_fused_lin (csrc/conv_lin.hip): rows packed at 24 K-bytes when the window allows it
+    npairs = kz * kx
+    w24 = pya - py + 15 + ky - 1 < 24 and os.environ.get("SN_CONV_LIN_NO24", "")[:1] != "1"
+    nsteps = (3 * npairs + 7) // 8 if w24 else (npairs + 1) // 2
+    tables = (nsteps + 1) * 3 * 1024 + 64 + ((nsteps + 3) * 32 if w24 else 0) + 16
+    halo = (((8 + kz - 1) * (16 + kx - 1) + 15) & ~15) * 80
+    scratch = ((kz * kx * ky + 3) & ~3) * 4 + kz * kx * 3 * 17 * 4
+    lds = tables + max(halo, scratch)
     return (x.dtype == torch.bool and x.dim() == 5 and x.shape[-1] % 4 == 0 and pya - py + 15 + ky - 1 < 32
             and lds <= 160 * 1024)
 

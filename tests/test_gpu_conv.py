@@ -347,6 +347,8 @@ def test_golden_forward_fused_linear(hip_device, golden_dir, tag):
     ((1, 1, 7, 19, 40), (3, 3, 17), 2),      # widest ky: window 15 + 16 = 31
     ((1, 1, 9, 33, 64), (9, 9, 9), 33),      # any G: the bank is combined before the convolution
     ((2, 1, 17, 17, 128), (9, 9, 9), 16),
+    ((1, 1, 12, 20, 64), (11, 9, 5), 4),     # 18 x 24 = 432 halo rows: beyond the 16 register passes of 25 rows
+    ((1, 1, 10, 18, 64), (9, 11, 3), 3),     # 16 x 26 = 416 halo rows
 ])
 def test_fused_linear_against_oracle_and_dense_kernel(hip_device, shape, ks, G):
     torch.manual_seed(hash((shape, ks, G)) % 2**31)
