@@ -118,12 +118,15 @@ int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lam
  *   relu(tanh(sum_g lambda_g conv3d(x, K_g))) == relu(tanh(conv3d(x, sum_g lambda_g K_g)))
  * (equal to 5e-16 in the reference's fp64; core/models/SCENE_Net.py:322-339).  One combined kernel
  * K* = sum_g lambda_g K_g (any G), 24-bit fixed point, Toeplitz-along-y implicit GEMM on v_mfma_i32_16x16x64_i8:
- * 0.48 MFMA per voxel at 9^3 instead of 3.  x: SN_OCC8 only ([B,1,Z,X,Y], values in {0,1}, Y % 4 == 0, ky <= 17);
+ * 0.375 MFMA per voxel at 9^3 (kernel rows packed at 24 K-bytes for ky <= 9; 0.48 otherwise) instead of 3.  x: SN_OCC8 only ([B,1,Z,X,Y], values in {0,1}, Y % 4 == 0, ky <= 17);
  * out [B,1,Z,X,Y] SN_F32 | SN_F64.  Returns SN_ERR_UNSUPPORTED for other inputs / shapes: call sn_conv_bank then.
  * Error vs the 16-kernel contraction: the fixed-point step of K* (<= 2^-23 max|K*| per tap) and fp32 rounding of
  * the combination, ~1e-6 on the output. */
 int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
                   int G, int kz, int kx, int ky, void* out, int out_dtype, sn_stream_t stream);
+/* 1 when sn_conv_fused serves a [B,1,Z,X,Y] SN_OCC8 grid with a [kz,kx,ky] kernel (Y % 4, the ky window, the tables and
+ * the halo within 160 KiB of LDS), else 0: the caller's dispatch predicate, from the same plan the launch uses. */
+int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int kx, int ky);
 
 /* SceneNet.forward for FLOAT grids that are usually binary occupancy -- what the reference itself feeds: f64 {0., 1.}
  * out of ToFullDense (core/datasets/torch_transforms.py:33-34).  One pass writes (x != 0) into occ_ws [B*Z*X*Y] bytes

@@ -33,6 +33,7 @@ SYMBOLS = {
     "sn_effective_lambdas": (c_int, [_P, _P, _I, _I, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sn_conv_fused": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "sn_conv_fused_supported": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
     "sn_forward_auto": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
     "sn_voxel_desc": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
@@ -165,20 +166,13 @@ def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tenso
 
 
 def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
-    """Shapes sn_conv_fused serves: binary occupancy, Y % 4 == 0, a 16-y strip's window within 32 bytes, tables in LDS."""
+    """Shapes sn_conv_fused serves: binary occupancy [B,1,Z,X,Y], and whatever the library's own plan accepts
+    (sn_conv_fused_supported: Y % 4 == 0, a 16-y strip's window within 32 bytes, tables + halo in LDS)."""
+    if x.dtype != torch.bool or x.dim() != 5:
+        return False
     kz, kx, ky = (int(k) for k in kernel_size)
-    py = (ky - 1) // 2
-    pya = (py + 3) & ~3
-    # mirrors sn::conv_fused_lin (csrc/conv_lin.hip): rows packed at 24 K-bytes when the window allows it
-    npairs = kz * kx
-    w24 = pya - py + 15 + ky - 1 < 24 and os.environ.get("SN_CONV_LIN_NO24", "")[:1] != "1"
-    nsteps = (3 * npairs + 7) // 8 if w24 else (npairs + 1) // 2
-    tables = (nsteps + 1) * 3 * 1024 + 64 + ((nsteps + 3) * 32 if w24 else 0) + 16
-    halo = (((8 + kz - 1) * (16 + kx - 1) + 15) & ~15) * 80
-    scratch = ((kz * kx * ky + 3) & ~3) * 4 + kz * kx * 3 * 17 * 4
-    lds = tables + max(halo, scratch)
-    return (x.dtype == torch.bool and x.dim() == 5 and x.shape[-1] % 4 == 0 and pya - py + 15 + ky - 1 < 32
-            and lds <= 160 * 1024)
+    B, _, Z, X, Y = x.shape
+    return bool(load().sn_conv_fused_supported(int(B), int(Z), int(X), int(Y), kz, kx, ky))
 
 
 def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,

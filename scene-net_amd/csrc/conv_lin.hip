@@ -497,26 +497,24 @@ int num_cus() {
 
 }  // namespace
 
-// returns SN_ERR_UNSUPPORTED (without touching the error text) when the shape is outside this kernel
-int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
-                       int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream) {
-    if (Y % 4 != 0 || ((uintptr_t)x % 4) || ((uintptr_t)out % 16)) return SN_ERR_UNSUPPORTED;
-    LinShape s;
+namespace {
+// The shape plan, shared by the launch and by sn_conv_fused_supported: false when the shape is outside this kernel.
+bool lin_plan(int B, int Z, int X, int Y, int G, int kz, int kx, int ky, LinShape& s, size_t& lds, bool& w24) {
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || kz <= 0 || kx <= 0 || ky <= 0 || Y % 4 != 0) return false;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G;
     s.kz = kz; s.kx = kx; s.ky = ky;
-    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
     s.pz = (kz - 1) / 2; s.px = (kx - 1) / 2; s.py = (ky - 1) / 2;
     s.PYA = (s.py + 3) & ~3;
-    if (s.PYA - s.py + 15 + ky - 1 >= 32) return SN_ERR_UNSUPPORTED;  // a 16-y strip's window must fit 32 halo bytes
-    if (TY - 16 + 32 > YB) return SN_ERR_UNSUPPORTED;
+    if (s.PYA - s.py + 15 + ky - 1 >= 32) return false;  // a 16-y strip's window must fit 32 halo bytes
+    if (TY - 16 + 32 > YB) return false;
     s.nzt = (Z + TZ - 1) / TZ; s.nxt = (X + TX - 1) / TX; s.nyt = (Y + TY - 1) / TY;
     const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
-    if (nt > 0x7fffffff) return SN_ERR_UNSUPPORTED;
+    if (nt > 0x7fffffff) return false;
     s.ntiles = (int)nt;
     s.npairs = kz * kx;
     // 24-byte packing of the kernel rows when a strip's window fits 24 halo bytes (ky <= 9 with PYA == py)
     const char* no24 = getenv("SN_CONV_LIN_NO24");
-    const bool w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !(no24 && no24[0] == '1');
+    w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !(no24 && no24[0] == '1');
     s.nsteps = w24 ? (3 * s.npairs + 7) / 8 : (s.npairs + 1) / 2;   // odd counts end with a lone step after the pairs
     s.XP = TX + kx - 1;
     s.rows = (TZ + kz - 1) * s.XP;
@@ -524,9 +522,28 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     const size_t halo = (size_t)s.NRP * YB;
     // prologue scratch aliasing the halo: K* and the padded digit rows
     const size_t kst = (((size_t)kz * kx * ky + 3) & ~(size_t)3) * sizeof(float) + (size_t)kz * kx * 3 * 17 * 4;
-    const size_t lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (w24 ? (size_t)(s.nsteps + 3) * 8 * 4 : 0) +
-                       (halo > kst ? halo : kst) + 16;
-    if (lds > (size_t)kMaxLds) return SN_ERR_UNSUPPORTED;
+    lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (w24 ? (size_t)(s.nsteps + 3) * 8 * 4 : 0) +
+          (halo > kst ? halo : kst) + 16;
+    return lds <= (size_t)kMaxLds;
+}
+}  // namespace
+
+extern "C" int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int kx, int ky) {
+    LinShape s;
+    size_t lds = 0;
+    bool w24 = false;
+    return lin_plan(B, Z, X, Y, 1, kz, kx, ky, s, lds, w24) ? 1 : 0;
+}
+
+// returns SN_ERR_UNSUPPORTED (without touching the error text) when the shape is outside this kernel
+int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
+                       int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream) {
+    if (((uintptr_t)x % 4) || ((uintptr_t)out % 16)) return SN_ERR_UNSUPPORTED;
+    LinShape s;
+    size_t lds = 0;
+    bool w24 = false;
+    if (!lin_plan(B, Z, X, Y, G, kz, kx, ky, s, lds, w24)) return SN_ERR_UNSUPPORTED;
+    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
     int grid = num_cus();
     if (grid > s.ntiles) grid = s.ntiles;
     s.dbg = getenv("SN_CONV_LIN_DBG") ? atoi(getenv("SN_CONV_LIN_DBG")) : 0;
