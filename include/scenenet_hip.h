@@ -278,7 +278,7 @@ int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, 
  * ------------------------------------------------------------------------- */
 #define SN_LOSS_MAX_BINS 16
 #define SN_LOSS_NSTAT(H) (3 * (H) + 5)   /* cnt[H], sq_err[H], sum_pt, sum_p, sum_t, sum_pp, sum_tt, bce[H] */
-#define SN_LOSS_PARTS(n_per) ((n_per) <= 8192 ? 1 : ((n_per) >= 8192 * 256 ? 256 : (int)(((n_per) + 8191) / 8192)))
+#define SN_LOSS_PARTS(n_per) ((n_per) <= 16384 ? 1 : ((n_per) >= 16384 * 256 ? 256 : (int)(((n_per) + 16383) / 16384)))
 #define SN_LOSS_WS_DOUBLES(B, n_per, H) ((int64_t)(B) * SN_LOSS_PARTS(n_per) * SN_LOSS_NSTAT(H))
 #define SN_LOSS_NCOEF(B) (2 * SN_LOSS_MAX_BINS + 3 * (B))
 typedef enum { SN_LOSS_WMSE = 1, SN_LOSS_FOCAL_TVERSKY = 2, SN_LOSS_DICE = 4, SN_LOSS_WBCE = 8 } sn_loss_term;

@@ -434,7 +434,7 @@ def effective_lambdas(lambdas: torch.Tensor, order: torch.Tensor, last: int) -> 
 # --------------------------------------------------------------------------- #
 def loss_parts(n_per: int) -> int:
     """SN_LOSS_PARTS of include/scenenet_hip.h."""
-    return 1 if n_per <= 8192 else min(256, (n_per + 8191) // 8192)
+    return 1 if n_per <= 16384 else min(256, (n_per + 16383) // 16384)
 
 
 def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int,
