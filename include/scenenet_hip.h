@@ -262,6 +262,15 @@ int sn_conv_corr_blocks(int B, int Z, int X, int Y);
 int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
                       const float* dW, float* dparams, sn_stream_t stream);
 
+/* The parameter side of SceneNet's backward in one launch, from the correlation C of sn_conv_corr (by linearity
+ * dL/dK_g = lambda_g C): dparams [G, SN_NPARAM] as sn_geneo_bank_bwd would give for dW_g = lambda_g C, and
+ * dlambdas [G] = <K_g, C> - <K_last, C> -- the gradient of the trainable convex coefficients when coefficient `last`
+ * is 1 - sum(others) (SCENE_Net.py:331; entry `last` comes out 0).  bank [G,kz,kx,ky] and lambdas [G] (effective
+ * coefficients) are the forward's. */
+int sn_geneo_backward(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, const float* bank,
+                      const float* lambdas, const float* corr, int last, float* dparams, float* dlambdas,
+                      sn_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * K5  training criterion on the prediction grid
  * replaces: WeightedMSE.forward + get_weight_target/get_dens_target (core/criterions/w_mse.py:114-151),

@@ -49,6 +49,7 @@ SYMBOLS = {
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sn_geneo_backward": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "sn_loss_forward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
                         + [_P, _P, _P, _P, _P]),
     "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
@@ -419,6 +420,23 @@ def geneo_bank_bwd(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Seque
                                   ky, _ptr(dW, torch.float32, "dW"), _ptr(dparams), _stream())
     _check(rc, "sn_geneo_bank_bwd")
     return dparams
+
+
+def geneo_backward(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int], bank: torch.Tensor,
+                   lambdas: torch.Tensor, corr: torch.Tensor, last: int, out: torch.Tensor) -> torch.Tensor:
+    """sn_geneo_backward: writes out[: G*SN_NPARAM] (dparams) and out[G*SN_NPARAM :] (dlambdas) of the packed gradient
+    vector in one launch, from the correlation `corr` [kz,kx,ky]."""
+    G = params.shape[0]
+    kz, kx, ky = (int(k) for k in kernel_size)
+    n = G * SN_NPARAM
+    if out.numel() != n + G or out.dtype != torch.float32:
+        raise HipLibraryError("packed gradient must be f32 [G*SN_NPARAM + G]")
+    base = _ptr(out, torch.float32, "out")
+    rc = load().sn_geneo_backward(_ptr(params, torch.float32, "params"), _ptr(kinds, torch.int32, "kinds"), G, kz, kx,
+                                  ky, _ptr(bank, torch.float32, "bank"), _ptr(lambdas, torch.float32, "lambdas"),
+                                  _ptr(corr, torch.float32, "corr"), int(last), base, base + 4 * n, _stream())
+    _check(rc, "sn_geneo_backward")
+    return out
 
 
 def effective_lambdas(lambdas: torch.Tensor, order: torch.Tensor, last: int) -> torch.Tensor:

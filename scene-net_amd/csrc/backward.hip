@@ -106,6 +106,13 @@ __global__ void corr_reduce_kernel(const float* __restrict__ partial, int nblk, 
 }
 
 // ---------------------------------------------------------------- generator Jacobians
+// a * b rounded to fp32 before anything is added to it (HIP's __fmul_rn is a plain product that hipcc contracts into an
+// fma with a following add)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -118,10 +125,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // one workgroup per GENEO: dparams[g][slot] = < P(dW_g), df/dslot >  (+ the neg_factor constant terms)
+// Fused form (sn_geneo_backward): dW_g = lambda_g C is formed on the fly from the correlation C, and the workgroup
+// also writes dL/dlambda_g - dL/dlambda_last, dL/dlambda_g = <K_g, C> (the frozen coefficient 1 - sum(others) hands
+// its gradient, negated, to every other one: SCENE_Net.py:331).
 __global__ __launch_bounds__(256) void geneo_bank_bwd_kernel(const float* __restrict__ params,
                                                              const int32_t* __restrict__ kinds, int kz, int kx,
                                                              int ky, const float* __restrict__ dW,
-                                                             float* __restrict__ dparams) {
+                                                             float* __restrict__ dparams,
+                                                             const float* __restrict__ corr,
+                                                             const float* __restrict__ lambdas,
+                                                             const float* __restrict__ bank, int last,
+                                                             float* __restrict__ dlam) {
     extern __shared__ float lds[];
     __shared__ float red[4];
     const int g = blockIdx.x, tid = threadIdx.x;
@@ -135,19 +149,20 @@ __global__ __launch_bounds__(256) void geneo_bank_bwd_kernel(const float* __rest
     const bool v1 = (kind >= SN_GENEO_CY_V1);
     const float radius = p[SN_P_RADIUS], sigma = p[SN_P_SIGMA];
     const float cx = (kx - 1) * 0.5f, cy = (ky - 1) * 0.5f, cz = (kz - 1) * 0.5f;
-    const float* dw = dW + (size_t)g * vol;
+    const float* dw = corr ? corr : dW + (size_t)g * vol;
+    const float dws = corr ? lambdas[g] : 1.0f;   // fused: dW_g[i] = lambda_g * C[i] (the product torch formed before)
 
     // P(dW): subtract the slice mean (cy / cone) or the global mean (neg)
     const int nseg = is_neg ? 1 : kz, seg_len = is_neg ? vol : nfloor;
     for (int s = tid >> 6; s < nseg; s += 4) {
         float a = 0.f;
-        for (int i = tid & 63; i < seg_len; i += 64) a += dw[s * seg_len + i];
+        for (int i = tid & 63; i < seg_len; i += 64) a += mul_rounded(dws, dw[s * seg_len + i]);   // the rounded product, as torch's lambda * C was
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
         if ((tid & 63) == 0) seg[s] = a;
     }
     __syncthreads();
-    for (int i = tid; i < vol; i += 256) dwc[i] = dw[i] - seg[is_neg ? 0 : i / nfloor] / (float)seg_len;
+    for (int i = tid; i < vol; i += 256) dwc[i] = mul_rounded(dws, dw[i]) - seg[is_neg ? 0 : i / nfloor] / (float)seg_len;
     __syncthreads();
     const float sum_dw = is_neg ? seg[0] : 0.f;
 
@@ -239,6 +254,18 @@ __global__ __launch_bounds__(256) void geneo_bank_bwd_kernel(const float* __rest
         if (kind == SN_GENEO_NEG) o[SN_P_NEG_FACTOR] = g_nf - sum_dw / (float)vol;  // W = P(f) - nf / vol
         if (kind == SN_GENEO_NEG_V1) o[SN_P_NEG_FACTOR] = -sum_dw;                  // W = P(f) - nf
     }
+    if (corr && dlam) {
+        float a = 0.f, b = 0.f;
+        const float* kg = bank + (size_t)g * vol;
+        const float* kl = bank + (size_t)last * vol;
+        for (int i = tid; i < vol; i += 256) {
+            a = fmaf(kg[i], corr[i], a);
+            b = fmaf(kl[i], corr[i], b);
+        }
+        a = block_sum(a, red);
+        b = block_sum(b, red);
+        if (tid == 0) dlam[g] = a - b;   // exactly 0 for g == last (same sums)
+    }
 }
 
 }  // namespace
@@ -290,6 +317,22 @@ extern "C" int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int 
     const long vol = (long)kz * kx * ky;
     if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank_bwd: kernel volume %ld > 12000", vol);
     hipLaunchKernelGGL(geneo_bank_bwd_kernel, dim3(G), dim3(256), (size_t)(vol + kz + 1) * sizeof(float),
-                       sn::as_stream(stream), params, kinds, kz, kx, ky, dW, dparams);
+                       sn::as_stream(stream), params, kinds, kz, kx, ky, dW, dparams, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
     return sn::check_launch("sn_geneo_bank_bwd");
+}
+
+extern "C" int sn_geneo_backward(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
+                                 const float* bank, const float* lambdas, const float* corr, int last,
+                                 float* dparams, float* dlambdas, sn_stream_t stream) {
+    if (!params || !kinds || !bank || !lambdas || !corr || !dparams || !dlambdas)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_backward: null pointer");
+    if (G <= 0 || kz <= 0 || kx <= 0 || ky <= 0 || last < 0 || last >= G)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_backward: bad extent / last");
+    const long vol = (long)kz * kx * ky;
+    if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_backward: kernel volume %ld > 12000", vol);
+    hipLaunchKernelGGL(geneo_bank_bwd_kernel, dim3(G), dim3(256), (size_t)(vol + kz + 1) * sizeof(float),
+                       sn::as_stream(stream), params, kinds, kz, kx, ky, (const float*)nullptr, dparams, corr, lambdas,
+                       bank, last, dlambdas);
+    return sn::check_launch("sn_geneo_backward");
 }

@@ -362,13 +362,10 @@ class _GeneoForwardFn(torch.autograd.Function):
         n = G * _hip.SN_NPARAM
         C = _hip.conv_corr(x, gout.to(torch.float32).contiguous(), out.to(torch.float32).contiguous(),
                            ctx.kernel_size)                      # [kz,kx,ky]
-        c = C.reshape(1, -1)
+        # dL/dK_g = lambda_g C and dL/dlambda_g = <K_g, C> (minus the frozen coefficient's, SCENE_Net.py:331), the
+        # generator Jacobians and the packing into gP: one launch
         gP = torch.empty_like(P)
-        dlam = torch.mv(bank.reshape(G, -1), c.reshape(-1))      # dL/dlambda_g(effective) = <K_g, C>
-        # lambda_last = 1 - sum(others): its gradient flows, negated, into every other coefficient (SCENE_Net.py:331)
-        torch.sub(dlam, dlam[ctx.last], out=gP[n:])
-        dW = (lam.reshape(G, 1) * c).reshape(bank.shape)         # dL/dK_g = lambda_g C
-        gP[:n] = _hip.geneo_bank_bwd(P[:n].view(G, _hip.SN_NPARAM), kinds, ctx.kernel_size, dW).reshape(-1)
+        _hip.geneo_backward(P[:n].view(G, _hip.SN_NPARAM), kinds, ctx.kernel_size, bank, lam, C, ctx.last, gP)
         return None, gP, None, None, None, None, None
 
 

@@ -44,6 +44,31 @@ def test_generator_jacobians(hip_device, kind, ks):
     assert got[_hip.SN_P_APEX].item() == 0.0
 
 
+@pytest.mark.parametrize("ks", [(9, 9, 9), (9, 5, 5)])
+def test_fused_parameter_backward_equals_its_parts(hip_device, ks):
+    """sn_geneo_backward == sn_geneo_bank_bwd on dW_g = lambda_g C (bit for bit) and <K_g, C> - <K_last, C>."""
+    torch.manual_seed(8)
+    kinds_l = ["cy", "cone", "neg", "cy", "neg"]
+    G, last = len(kinds_l), 3
+    P = torch.stack([pack_params(KIND_OF_CLASS[k], {n: v * (1 + 0.07 * i) if n != "apex" else v
+                                                    for n, v in PARAMS[k].items()}, hip_device)
+                     for i, k in enumerate(kinds_l)]).contiguous()
+    kinds = torch.tensor([KIND_OF_CLASS[k] for k in kinds_l], dtype=torch.int32, device=hip_device)
+    bank = _hip.geneo_bank(P, kinds, ks)
+    lam = (torch.rand(G, device=hip_device) - 0.3).contiguous()
+    C = torch.randn(ks, device=hip_device).contiguous()
+    out = torch.full((G * _hip.SN_NPARAM + G,), float("nan"), device=hip_device)
+    _hip.geneo_backward(P, kinds, ks, bank, lam, C, last, out)
+    dW = (lam.reshape(G, 1) * C.reshape(1, -1)).reshape(bank.shape).contiguous()
+    parts = _hip.geneo_bank_bwd(P, kinds, ks, dW)
+    assert torch.equal(out[: G * _hip.SN_NPARAM].view(G, _hip.SN_NPARAM), parts)
+    dlam = (bank.reshape(G, -1).double() @ C.reshape(-1).double())
+    want = (dlam - dlam[last]).float()
+    got = out[G * _hip.SN_NPARAM:]
+    assert got[last].item() == 0.0
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4 * float(dlam.abs().max()))
+
+
 def test_correlation_kernel(hip_device):
     """C[t] = sum delta * shifted x  ==  the weight gradient of a 1-kernel conv3d."""
     torch.manual_seed(5)
