@@ -95,6 +95,11 @@ int sn_geneo_bank(const float* params, const int32_t* kinds, int G, int kz, int 
  * yields.  lambdas [G] f32 is in/out: lambdas[last] is overwritten with out[last], the side effect of
  * SCENE_Net.py:333 (the frozen parameter is refreshed by every forward).  order [G] i32, out [G] f32. */
 int sn_effective_lambdas(float* lambdas, const int32_t* order, int G, int last, float* out, sn_stream_t stream);
+/* sn_geneo_bank and sn_effective_lambdas in one launch (the two openers of a training forward: both read the packed
+ * parameter vector, neither depends on the other). */
+int sn_geneo_bank_lambdas(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                          int32_t* status, float* lambdas, const int32_t* order, int last, float* lambdas_out,
+                          sn_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * K3  GENEO bank convolution + convex-combination head

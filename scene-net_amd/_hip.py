@@ -48,6 +48,7 @@ SYMBOLS = {
     "sn_grid_to_points": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
+    "sn_geneo_bank_lambdas": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_geneo_backward": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "sn_loss_forward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
@@ -143,6 +144,21 @@ def geneo_bank(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[
                               _ptr(out, torch.float32, "bank"), _ptr(status, torch.int32, "status"), _stream())
     _check(rc, "sn_geneo_bank")
     return out
+
+
+def geneo_bank_lambdas(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int], lambdas: torch.Tensor,
+                       order: torch.Tensor, last: int):
+    """sn_geneo_bank_lambdas: (bank [G,kz,kx,ky], effective coefficients [G]) in one launch; `lambdas[last]` is
+    refreshed in place like sn_effective_lambdas does."""
+    G = params.shape[0]
+    kz, kx, ky = (int(k) for k in kernel_size)
+    bank = torch.empty((G, kz, kx, ky), dtype=torch.float32, device=params.device)
+    lam = torch.empty((G,), dtype=torch.float32, device=params.device)
+    rc = load().sn_geneo_bank_lambdas(_ptr(params, torch.float32, "params"), _ptr(kinds, torch.int32, "kinds"), G, kz,
+                                      kx, ky, _ptr(bank), None, _ptr(lambdas, torch.float32, "lambdas"),
+                                      _ptr(order, torch.int32, "order"), int(last), _ptr(lam), _stream())
+    _check(rc, "sn_geneo_bank_lambdas")
+    return bank, lam
 
 
 def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tensor], want_act: bool = False,

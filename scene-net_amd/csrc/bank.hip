@@ -34,13 +34,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// SCENE_Net.py:329-335: the frozen coefficient is 1 - sum(all, in ParameterDict order) + itself, a sequential fp32
+// sum; one thread reproduces it bit for bit.  Also stores it back (the reference re-creates that parameter).
+__device__ void effective_lambdas_thread(float* __restrict__ lambdas, const int32_t* __restrict__ order, int G,
+                                         int last, float* __restrict__ out) {
+    float total = 0.f;
+    for (int i = 0; i < G; ++i) total = __fadd_rn(total, lambdas[order[i]]);
+    const float eff = __fadd_rn(__fsub_rn(1.0f, total), lambdas[last]);
+    for (int g = 0; g < G; ++g) out[g] = (g == last) ? eff : lambdas[g];
+    lambdas[last] = eff;
+}
+
+// grid G (+ 1 when the effective coefficients ride along: sn_geneo_bank_lambdas; that extra workgroup does them)
 __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __restrict__ params,
                                                               const int32_t* __restrict__ kinds, int kz, int kx,
                                                               int ky, float* __restrict__ bank,
-                                                              int32_t* __restrict__ status) {
+                                                              int32_t* __restrict__ status, int G,
+                                                              float* __restrict__ lambdas,
+                                                              const int32_t* __restrict__ order, int last,
+                                                              float* __restrict__ lambdas_out) {
     extern __shared__ float lds[];
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
+    if (g >= G) {
+        if (tid == 0 && lambdas) effective_lambdas_thread(lambdas, order, G, last, lambdas_out);
+        return;
+    }
     const int nfloor = kx * ky;
     const int vol = kz * nfloor;
     float* vals = lds;          // [vol]
@@ -125,16 +144,10 @@ __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __res
     }
 }
 
-// SCENE_Net.py:329-335: the frozen coefficient is 1 - sum(all, in ParameterDict order) + itself, a sequential fp32
-// sum; one thread reproduces it bit for bit.  Also stores it back (the reference re-creates that parameter).
 __global__ void effective_lambdas_kernel(float* __restrict__ lambdas, const int32_t* __restrict__ order, int G,
                                          int last, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float total = 0.f;
-    for (int i = 0; i < G; ++i) total = __fadd_rn(total, lambdas[order[i]]);
-    const float eff = __fadd_rn(__fsub_rn(1.0f, total), lambdas[last]);
-    for (int g = 0; g < G; ++g) out[g] = (g == last) ? eff : lambdas[g];
-    lambdas[last] = eff;
+    effective_lambdas_thread(lambdas, order, G, last, out);
 }
 
 }  // namespace
@@ -157,6 +170,21 @@ extern "C" int sn_geneo_bank(const float* params, const int32_t* kinds, int G, i
     if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank: kernel volume %ld > 12000", vol);
     size_t lds = (size_t)(vol + kz + 1) * sizeof(float);
     hipLaunchKernelGGL(geneo_bank_kernel, dim3(G), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz, kx,
-                       ky, bank, status);
+                       ky, bank, status, G, (float*)nullptr, (const int32_t*)nullptr, 0, (float*)nullptr);
     return sn::check_launch("sn_geneo_bank");
+}
+
+extern "C" int sn_geneo_bank_lambdas(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,
+                                     float* bank, int32_t* status, float* lambdas, const int32_t* order, int last,
+                                     float* lambdas_out, sn_stream_t stream) {
+    if (!params || !kinds || !bank || !lambdas || !order || !lambdas_out)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank_lambdas: null pointer");
+    if (G <= 0 || kz <= 0 || kx <= 0 || ky <= 0 || last < 0 || last >= G)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank_lambdas: bad extent / last");
+    const long vol = (long)kz * kx * ky;
+    if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank_lambdas: kernel volume %ld > 12000", vol);
+    size_t lds = (size_t)(vol + kz + 1) * sizeof(float);
+    hipLaunchKernelGGL(geneo_bank_kernel, dim3(G + 1), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz,
+                       kx, ky, bank, status, G, lambdas, order, last, lambdas_out);
+    return sn::check_launch("sn_geneo_bank_lambdas");
 }

@@ -339,8 +339,7 @@ class _GeneoForwardFn(torch.autograd.Function):
         G = meta["G"]
         n = G * _hip.SN_NPARAM
         p = flat[:n].view(G, _hip.SN_NPARAM)
-        lam = _hip.effective_lambdas(flat[n:], meta["order"], meta["last"])
-        bank = _hip.geneo_bank(p, meta["kinds"], kernel_size)
+        bank, lam = _hip.geneo_bank_lambdas(p, meta["kinds"], kernel_size, flat[n:], meta["order"], meta["last"])
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
         if fused and not want_act and _hip.conv_fused_supported(x, kernel_size):
             act, out = None, _hip.conv_fused(x, bank, lam, out_dtype=out_dtype)   # forward through linearity
