@@ -35,8 +35,9 @@ from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthe
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_I8_MFMA_TOPS = 5000.0     # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-MEASURED_I8_MFMA_TOPS = 3500.0  # tools/micro/mfma_i8_peak.hip: a loop of nothing but independent i8 MFMAs on RANDOM operands
-                                # sustains 3.4-3.6 POP/s (4.4-4.55 on constant operands: the chip clocks down with toggling)
+MEASURED_I8_MFMA_TOPS = 4050.0  # tools/micro/mfma_i8_peak.hip: a loop of nothing but independent i8 MFMAs on RANDOM operands
+                                # sustains 4.0-4.06 POP/s once the clocks have settled (3.5-3.7 started cold; 4.7-4.8 on
+                                # constant operands: the chip clocks down with operand toggling)
 GENEO_NUM = {"cy": 6, "cone": 5, "neg": 5}
 KERNEL_SIZE = (9, 9, 9)
 
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--spinup-ms", type=float, default=200.0,
+                    help="untimed spin-up of the same step before the warm-up steps (device clocks settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 code path on a one-GPU box: every rank uses cuda:0, process group over gloo (not a "
@@ -170,10 +173,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def spin(fn, ms):
+        """untimed: run fn under sustained load for `ms` so the device clocks are where a long job would have them"""
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < ms:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+
     # host hygiene: a full python GC pass over torch's ~10^6 objects costs tens of ms and would land at a random
     # point of the timed loop; park everything allocated so far in the permanent generation
     gc.collect()
     gc.freeze()
+    # device hygiene: the chip's clocks take ~100 ms of sustained load to settle after idling ([measured] the same
+    # kernels: 0.317 ms/launch in a 20-step run started cold, 0.296 in the second half of a 100-step run); the
+    # untimed spin-up runs the same step until that much GPU time has passed, then the W warm-up steps follow
+    if args.spinup_ms > 0:
+        spin(lambda: step(False), args.spinup_ms)
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -224,6 +240,7 @@ def main():
             out_skip = None
             for _ in range(3):   # also grows torch's allocator to the two extra output blocks the loop below ping-pongs
                 out_skip = step(False)
+            spin(lambda: step(False), args.spinup_ms / 4)
             torch.cuda.synchronize()
             ts = time.perf_counter()
             for _ in range(n32):
@@ -249,6 +266,7 @@ def main():
         out_fused = None
         for _ in range(3):
             out_fused = fused_step()
+        spin(fused_step, args.spinup_ms / 4)
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for _ in range(nf):
@@ -288,6 +306,7 @@ def main():
             out_graph = step(False)
         for _ in range(3):
             graph.replay()
+        spin(graph.replay, args.spinup_ms / 4)
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for _ in range(args.steps):
@@ -307,6 +326,7 @@ def main():
                 out_fg = fused_step()
             for _ in range(3):
                 fgraph.replay()
+            spin(fgraph.replay, args.spinup_ms / 4)
             torch.cuda.synchronize()
             ts = time.perf_counter()
             for _ in range(nf):

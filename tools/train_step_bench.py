@@ -5,6 +5,7 @@ import argparse
 import gc
 import os
 import sys
+import time
 
 import torch
 
@@ -14,9 +15,14 @@ from scene_net_amd import _hip  # noqa: E402
 from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile  # noqa: E402
 
 
-def timed(fn, iters, warm=2):
+def timed(fn, iters, warm=2, spin_ms=150.0):
     gc.collect()
     gc.freeze()   # keep Python's full GC passes out of the timed loop
+    t_spin = time.perf_counter()   # the chip's clocks settle after ~100 ms of sustained load (see bench.py)
+    while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
