@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscenenet_hip.so")
+# SN_HIP_LIB: another build of the same library (A/B timing of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get("SN_HIP_LIB") or os.path.join(_HERE, "lib", "libscenenet_hip.so")
 
 SN_F32, SN_F64, SN_U8, SN_OCC8 = 0, 1, 2, 3
 SN_GENEO_CY, SN_GENEO_CONE, SN_GENEO_NEG = 0, 1, 2
