@@ -63,6 +63,12 @@ def main():
     for _ in range(3):
         per_point, grids = step()
     torch.cuda.synchronize()
+    import time as _time
+    _t = _time.perf_counter()   # the chip's clocks settle after ~100 ms of sustained load (see bench.py)
+    while _time.perf_counter() - _t < 0.15:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     for _ in range(args.iters):
