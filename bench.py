@@ -338,7 +338,8 @@ def main():
             fused_info["graph_replay_identical_output"] = bool(torch.equal(out_fg, out_fused))
             del fgraph
     except Exception as exc:  # noqa: BLE001 -- an extra, never fatal to the headline
-        graph_info = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        msg = f"{type(exc).__name__}: {exc}"[:200]
+        graph_info = {"skipped": msg} if "skipped" in msg else {"error": msg}
 
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from separate rocprofv3 --pmc passes
