@@ -230,3 +230,25 @@ def test_scene_net_picks_the_linear_forward_only_for_what_it_serves():
     assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 8), dtype=torch.bool), (3, 3, 19))    # window > 32 bytes
     assert not _hip.conv_fused_supported(torch.zeros((1, 1, 8, 8, 8), dtype=torch.bool), (13, 13, 9))   # table > LDS
     assert sna.SceneNet.fused_forward is True
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01_final_bench.json (stdout of bench.py on the MI355X box) carries every key the driver's contract names,
+    the roofline and CPU-baseline objects, and internally consistent figures."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_final_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "tiles/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    tiles = d["config"]["tiles_per_gpu"] * d["n_gpus"]
+    assert abs(d["value"] - tiles / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is None or r["traffic"] > 0
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
