@@ -17,20 +17,24 @@ place this file touches oracle/) timed on the host cores on a bounded sample.
 """
 import argparse
 import gc
+import importlib.util
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import scene_net_amd as sna  # noqa: E402
-from scene_net_amd.pipeline import job_sum, job_time_max  # noqa: E402
-from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile  # noqa: E402
+
+def _load_launcher():
+    """scene-net_amd/launch.py by path: stdlib only, so the launching parent never imports torch or the HIP library
+    (children must be started by a process that has not initialised the device)."""
+    spec = importlib.util.spec_from_file_location("_sn_launch", os.path.join(ROOT, "scene-net_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_I8_MFMA_TOPS = 5000.0     # MI355X_MICROARCH.md: i8 MFMA = 2x the bf16 rate per clock, bf16 ~2.5 PF dense
@@ -59,6 +63,17 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the graph-replay and skip-empty extras (profiling runs: keeps per-kernel averages clean)")
     return ap.parse_args()
+
+
+def launch_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher above it (torchrun sets RANK/WORLD_SIZE): start the N
+    ranks ourselves -- fresh children, one per GPU, before this process has made any GPU call -- and exit with their
+    verdict.  Under torchrun (the driver's N > 1 form) this is a no-op."""
+    launch = _load_launcher()
+    if args.gpus <= 1 or launch.under_launcher():
+        return
+    rc = launch.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    sys.exit(rc)
 
 
 def host_cores():
@@ -114,22 +129,45 @@ def cpu_baseline(args, specs, names, lambdas, last, budget_s=20.0):
     }
 
 
+def _late_imports():
+    """torch / numpy / the package, imported only in a process that is a rank (never in the launching parent)."""
+    global np, torch, sna, job_sum, job_time_max, apply_bank_spec, synthetic_bank_spec, synthetic_tile
+    import numpy as np
+    import torch
+    import scene_net_amd as sna
+    from scene_net_amd.pipeline import job_sum, job_time_max
+    from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile
+
+
 def main():
     args = parse()
+    launch_if_needed(args)
+    _late_imports()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+              f"(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+    need = 1 if args.rehearse_on_one_gpu else local_rank + 1
+    if torch.cuda.device_count() < need:
+        print(f"bench.py: rank {rank} needs HIP device {need - 1}, {torch.cuda.device_count()} visible",
+              file=sys.stderr)
+        sys.exit(3)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path)"
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL; used only for barrier + max/sum of scalars
+        rccl_ranks = dist.get_world_size()
     n_gpus = world
 
     # ---- model with explicit parameters (SURVEY 8d) and this rank's resident batch
@@ -167,11 +205,30 @@ def main():
             conv_ev.append((c0, c))
         return out
 
+    def step_fp32():
+        """the same step with the contraction on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32): the occupancy bytes
+        are handed over as u8, which sn_conv_bank takes as a general (non-binary) input"""
+        grids = pipe.voxelize(batch)
+        bank = model.compute_bank(dev)
+        lam = model.effective_lambdas(dev)
+        return sna._hip.conv_bank(grids.occ.view(torch.uint8), bank, lam, want_act=False, want_out=True)[1]
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    def timed_job(fn, n):
+        """EXACTLY n steps of fn between two (barrier + synchronize) fences; returns (max-over-ranks seconds, this
+        rank's seconds)."""
+        fence()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        local = time.perf_counter() - t_
+        return job_time_max(local, dev), local
 
     def spin(fn, ms):
         """untimed: run fn under sustained load for `ms` so the device clocks are where a long job would have them"""
@@ -185,7 +242,12 @@ def main():
     # point of the timed loop; park everything allocated so far in the permanent generation
     gc.collect()
     gc.freeze()
-    # device hygiene: the chip's clocks take ~100 ms of sustained load to settle after idling ([measured] the same
+    # ---- cold figure first: W warm-up steps (lazy initialisation, allocator growth -- ~2 ms of GPU work after the
+    # seconds of idling the set-up above took), then K steps timed with the clocks wherever that leaves them
+    for _ in range(args.warmup):
+        step(False)
+    dt_cold, _ = timed_job(lambda: step(False), args.steps)
+    # ---- headline: the chip's clocks take ~100 ms of sustained load to settle after idling ([measured] the same
     # kernels: 0.317 ms/launch in a 20-step run started cold, 0.296 in the second half of a 100-step run); the
     # untimed spin-up runs the same step until that much GPU time has passed, then the W warm-up steps follow
     if args.spinup_ms > 0:
@@ -200,6 +262,18 @@ def main():
     dt_local = time.perf_counter() - t0
     dt = job_time_max(dt_local, dev)
     tiles_done = job_sum(float(B * args.steps), dev)
+    if world > 1:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, B * args.steps / dt_local)
+    else:
+        per_rank = [B * args.steps / dt_local]
+    # ---- the same job on the fp32 matrix pipe, end to end (K1 -> K2 -> fp32 conv + head), same loop, same fences
+    n32 = max(3, min(10, args.steps))
+    for _ in range(2):
+        step_fp32()
+    if args.spinup_ms > 0:
+        spin(step_fp32, args.spinup_ms / 4)
+    dt_fp32, _ = timed_job(step_fp32, n32)
 
     conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
     vox_ms = float(np.mean([a.elapsed_time(b) for a, b in vox_ev]))
@@ -223,7 +297,6 @@ def main():
         sna._hip.conv_bank(occ_u8, bank, lam, want_act=False, want_out=True)
     e0, e1 = ev(), ev()
     e0.record()
-    n32 = max(3, min(10, args.steps))
     for _ in range(n32):
         sna._hip.conv_bank(occ_u8, bank, lam, want_act=False, want_out=True)
     e1.record()
@@ -294,15 +367,16 @@ def main():
     try:
         if args.no_extras:
             raise RuntimeError("skipped (--no-extras)")
-        if world > 1:   # a process group's watchdog thread may touch the device mid-capture: single-process only
-            raise RuntimeError("skipped (world_size > 1)")
+        # under a live process group the RCCL watchdog thread may call into HIP while this thread captures: relaxed
+        # (thread-local) capture mode keeps its calls out of the capture's legality checks
+        cap_mode = "thread_local" if world > 1 else "global"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             step(False)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode=cap_mode):
             out_graph = step(False)
         for _ in range(3):
             graph.replay()
@@ -322,7 +396,7 @@ def main():
                 fused_step()
             torch.cuda.current_stream().wait_stream(side)
             fgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fgraph):
+            with torch.cuda.graph(fgraph, capture_error_mode=cap_mode):
                 out_fg = fused_step()
             for _ in range(3):
                 fgraph.replay()
@@ -352,6 +426,12 @@ def main():
         "value": tiles_done / dt, "unit": "tiles/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "i8", "data": "synthetic",
+        # the same K steps timed BEFORE the spin-up (clocks as the set-up left them), and the same job with the
+        # contraction on the fp32 matrix pipe (K1 -> K2 -> conv_bank_kernel, same fences, same batch)
+        "value_cold": tiles_done / dt_cold, "ms_per_step_cold": dt_cold / args.steps * 1e3,
+        "value_fp32": B * n32 * n_gpus / dt_fp32, "ms_per_step_fp32": dt_fp32 / n32 * 1e3, "steps_fp32": n32,
+        "clock_state": f"value: after {args.spinup_ms:.0f} ms untimed spin-up of the same step; value_cold: none",
+        "rccl_ranks": rccl_ranks, "per_rank_tiles_per_s": per_rank,
         "config": {"workload": f"C2: {B} tiles/GPU x {args.points} points (fp64 xyz, UTM-scale), {args.grid}^3 voxel "
                                f"grid, {G} GENEO kernels {KERNEL_SIZE[0]}^3 (cy 6, cone 5, neg 5); conv on the int8 "
                                f"matrix cores: binary occupancy x 24-bit fixed-point weights (3 int8 digits), exact "

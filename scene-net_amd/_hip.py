@@ -6,6 +6,7 @@ device, the call raises.  PyTorch is used only for device memory and streams.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 from ctypes import c_char_p, c_int, c_void_p
 from typing import Optional, Sequence
@@ -128,12 +129,45 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _common_device(tensors) -> Optional[torch.device]:
+    """The one HIP device every tensor argument of a C-ABI call lives on (None when there is no device tensor).
+    Raises on a mix: the library takes raw pointers and ONE stream, so operands on different devices would be
+    dereferenced from the wrong device."""
+    dev = None
+    for t in tensors:
+        if t is None or not getattr(t, "is_cuda", False):
+            continue   # CPU tensors are rejected with their own message by _ptr
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise HipLibraryError(f"tensor arguments live on different devices ({dev} and {t.device}); "
+                                  "a call of the C ABI runs on one device and one stream")
+    return dev
+
+
+def _on_tensor_device(fn):
+    """Runs a wrapper with the HIP device of its tensor arguments current, so `_stream()` (torch's current stream on
+    the CURRENT device) and the launch itself match the pointers -- `model.to('cuda:1')` while cuda:0 is current would
+    otherwise launch on device 0 with device-1 pointers.  One dictionary-free pass over the arguments when the devices
+    already agree (the torchrun / set_device case)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = _common_device([a for a in args if isinstance(a, torch.Tensor)]
+                             + [a for a in kwargs.values() if isinstance(a, torch.Tensor)])
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
 # torch.bool (one byte, 0/1) is the binary-occupancy dtype: sn_conv_bank takes it on the int8 matrix cores
 _DT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_OCC8}
 _DT_OUT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_U8}
 
 
 # --------------------------------------------------------------------------- #
+@_on_tensor_device
 def geneo_bank(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int],
                status: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """params [G, SN_NPARAM] f32, kinds [G] i32 -> bank [G, kz, kx, ky] f32 (sn_geneo_bank)."""
@@ -147,6 +181,7 @@ def geneo_bank(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[
     return out
 
 
+@_on_tensor_device
 def geneo_bank_lambdas(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int], lambdas: torch.Tensor,
                        order: torch.Tensor, last: int):
     """sn_geneo_bank_lambdas: (bank [G,kz,kx,ky], effective coefficients [G]) in one launch; `lambdas[last]` is
@@ -162,6 +197,7 @@ def geneo_bank_lambdas(params: torch.Tensor, kinds: torch.Tensor, kernel_size: S
     return bank, lam
 
 
+@_on_tensor_device
 def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tensor], want_act: bool = False,
               want_out: bool = True, out_dtype: Optional[torch.dtype] = None):
     """x [B,1,Z,X,Y] (f32|f64|u8|bool), bank [G,kz,kx,ky] f32, lambdas [G] f32 (effective) ->
@@ -193,6 +229,7 @@ def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
     return bool(load().sn_conv_fused_supported(int(B), int(Z), int(X), int(Y), kz, kx, ky))
 
 
+@_on_tensor_device
 def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """relu(tanh(conv3d(x, sum_g lambda_g K_g))) [B,1,Z,X,Y] (sn_conv_fused): the forward output through linearity."""
@@ -206,12 +243,15 @@ def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
     return out
 
 
+@_on_tensor_device
 def forward_auto(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor, out_dtype: Optional[torch.dtype] = None):
     """sn_forward_auto: the forward output for a float grid; binary grids (the reference's f64 {0,1} input) take the
     int8 path, anything else the fp32 contraction, decided on the device.  Returns (out, not_binary flag [1] i32)."""
     B, _, Z, X, Y = x.shape
     G, kz, kx, ky = bank.shape
     out_dtype = x.dtype if out_dtype is None else out_dtype
+    if x.data_ptr() % 16:   # a sliced view (x[1:] of an odd-sized grid): the binary check reads 16-byte vectors
+        x = x.clone()
     out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device)
     occ = torch.empty((x.numel(),), dtype=torch.uint8, device=x.device)
     flag = torch.empty((1,), dtype=torch.int32, device=x.device)
@@ -226,6 +266,7 @@ def desc_len(nx: int, ny: int, nz: int) -> int:
     return 6 + nx + ny + nz + 3
 
 
+@_on_tensor_device
 def voxel_bbox(pts: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     B = offsets.numel() - 1
     bbox = torch.empty((B, 6), dtype=torch.float64, device=pts.device)
@@ -235,6 +276,7 @@ def voxel_bbox(pts: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     return bbox
 
 
+@_on_tensor_device
 def voxel_prepare(pts: torch.Tensor, offsets: torch.Tensor, n_xyz: Sequence[int], regular: bool = True,
                   want_bbox: bool = False):
     """bbox + cube + linspace edge tables in two launches (sn_voxel_prepare): returns (desc, bbox | None)."""
@@ -250,6 +292,7 @@ def voxel_prepare(pts: torch.Tensor, offsets: torch.Tensor, n_xyz: Sequence[int]
     return desc, bbox
 
 
+@_on_tensor_device
 def voxel_desc(bbox: torch.Tensor, n_xyz: Sequence[int], regular: bool = True, from_bounds: bool = False):
     B = bbox.shape[0]
     nx, ny, nz = (int(v) for v in n_xyz)
@@ -264,6 +307,7 @@ def voxel_desc(bbox: torch.Tensor, n_xyz: Sequence[int], regular: bool = True, f
     return desc
 
 
+@_on_tensor_device
 def voxel_scatter(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[float] = (), want_towers: bool = False,
                   counts=None, towers=None, dropped=None):
     B = offsets.numel() - 1
@@ -285,6 +329,7 @@ def voxel_scatter(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[float
     return counts, (towers if want_towers else None), dropped
 
 
+@_on_tensor_device
 def voxel_finalize(counts, towers, want_density=False, want_gt=False, want_occ=True, want_gt_occ=False):
     B, nz, nx, ny = counts.shape
     dev = counts.device
@@ -315,6 +360,7 @@ def occupancy_supported(n_xyz: Sequence[int], planes: int) -> bool:
     return False
 
 
+@_on_tensor_device
 def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[float] = (), want_gt_occ: bool = False,
                     out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True):
     """LDS-bitmap occupancy (sn_voxel_occupancy): returns (occ, gt_occ | None, flags, dropped), grids [B,1,nz,nx,ny]."""
@@ -343,6 +389,7 @@ def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[flo
     return occ, gt_occ, flags, dropped
 
 
+@_on_tensor_device
 def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, keep_labels: Sequence[float] = (),
                           want_gt_occ: bool = False, out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True,
                           want_bbox: bool = False):
@@ -377,6 +424,7 @@ def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, kee
     return occ, gt_occ, flags, dropped, desc, bbox
 
 
+@_on_tensor_device
 def gather_points(grid: torch.Tensor, pts: torch.Tensor, offsets: torch.Tensor, desc: torch.Tensor,
                   fill: float = 0.0) -> torch.Tensor:
     """grid [B,C,nz,nx,ny] (f32|f64) -> per-point values [C, total] via the scatter's binning (sn_gather_points)."""
@@ -391,6 +439,7 @@ def gather_points(grid: torch.Tensor, pts: torch.Tensor, offsets: torch.Tensor, 
     return out
 
 
+@_on_tensor_device
 def grid_to_points(grid: torch.Tensor, origin=None, voxel_size=None) -> torch.Tensor:
     """grid [n0,n1,n2] (f32|f64|u8|bool) -> rows [n0*n1*n2, 4] f64 = (origin + index * voxel_size, value), C order of
     the indices (sn_grid_to_points; utils/voxelization.py:328-360)."""
@@ -415,6 +464,7 @@ def grid_to_points(grid: torch.Tensor, origin=None, voxel_size=None) -> torch.Te
     return out
 
 
+@_on_tensor_device
 def conv_corr(x: torch.Tensor, gout: torch.Tensor, out: Optional[torch.Tensor], kernel_size: Sequence[int]):
     """C [kz,kx,ky] f32 = sum_{b,v} delta[b,v] x[b, v+t-p]  (sn_conv_corr); gout/out [B,1,Z,X,Y] f32."""
     B, _, Z, X, Y = x.shape
@@ -428,6 +478,7 @@ def conv_corr(x: torch.Tensor, gout: torch.Tensor, out: Optional[torch.Tensor], 
     return C
 
 
+@_on_tensor_device
 def geneo_bank_bwd(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int], dW: torch.Tensor):
     """dparams [G, SN_NPARAM] f32 from dW [G,kz,kx,ky] f32 (sn_geneo_bank_bwd)."""
     G = params.shape[0]
@@ -439,6 +490,7 @@ def geneo_bank_bwd(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Seque
     return dparams
 
 
+@_on_tensor_device
 def geneo_backward(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Sequence[int], bank: torch.Tensor,
                    lambdas: torch.Tensor, corr: torch.Tensor, last: int, out: torch.Tensor) -> torch.Tensor:
     """sn_geneo_backward: writes out[: G*SN_NPARAM] (dparams) and out[G*SN_NPARAM :] (dlambdas) of the packed gradient
@@ -456,6 +508,7 @@ def geneo_backward(params: torch.Tensor, kinds: torch.Tensor, kernel_size: Seque
     return out
 
 
+@_on_tensor_device
 def effective_lambdas(lambdas: torch.Tensor, order: torch.Tensor, last: int) -> torch.Tensor:
     """sn_effective_lambdas: [G] f32 effective coefficients; `lambdas[last]` is refreshed in place."""
     G = int(lambdas.numel())
@@ -472,6 +525,7 @@ def loss_parts(n_per: int) -> int:
     return 1 if n_per <= 16384 else min(256, (n_per + 16383) // 16384)
 
 
+@_on_tensor_device
 def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int,
                  mse_weight: float = 1.0, tversky_alpha: float = 0.5, tversky_beta: float = 1.0,
                  focal_gamma: float = 1.0, tversky_smooth: float = 1.0, dice_smooth: float = 1.0):
@@ -496,6 +550,7 @@ def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin
     return loss, stats, coef
 
 
+@_on_tensor_device
 def loss_backward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, coef: torch.Tensor,
                   upstream: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/dpred (pred's dtype and shape) from the coefficients of loss_forward (sn_loss_backward)."""
@@ -510,6 +565,7 @@ def loss_backward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, co
     return grad
 
 
+@_on_tensor_device
 def param_penalty(P: torch.Tensor, mask: torch.Tensor, weight: float, with_sum: bool):
     """sn_param_penalty: (value [1] f32, grad [N] f32) of the GENEO_Loss penalties over the packed parameters."""
     N = int(P.numel())

@@ -6,12 +6,38 @@ density and the ground-truth grid; the reference voxelises the same points twice
 """
 from __future__ import annotations
 
+import warnings
 from typing import Tuple
 
 import numpy as np
 import torch
 
+from . import _hip
 from . import voxelization as Vox
+
+_warned_worker = False
+
+
+def _check_worker_context():
+    """The reference runs this transform inside DataLoader workers (`num_workers: 8`, fork start method:
+    core/lit_modules/lit_data_wrappers.py:62-72).  A HIP context does not survive a fork: in a worker forked after
+    the parent touched the GPU every HIP call fails, so say what to do instead of torch's generic re-initialisation
+    error.  In a worker that CAN use the device (spawned, or forked before any GPU call) the transform works but pays
+    a HIP context per worker and a per-tile H2D + sync + D2H: warn once and point at the batch-side form."""
+    global _warned_worker
+    if torch.cuda._is_in_bad_fork():
+        raise _hip.HipLibraryError(
+            "Voxelization was called in a process forked after the parent initialised the GPU (a DataLoader worker "
+            "with the default 'fork' start method): a HIP context cannot be used there.  Use num_workers=0, or "
+            "DataLoader(..., multiprocessing_context='spawn'), or -- better -- let the workers only load the .npy "
+            "tiles and voxelise the whole batch on the device with scene_net_amd.voxelize_batch / ScenePipeline "
+            "(INTEGRATION.md section 1)")
+    if not _warned_worker and torch.utils.data.get_worker_info() is not None:
+        _warned_worker = True
+        warnings.warn("scene_net_amd.Voxelization is running inside a DataLoader worker: every worker holds its own "
+                      "HIP context and pays H2D + sync + D2H per tile (about 2 ms/tile).  Voxelise batch-side "
+                      "instead (scene_net_amd.voxelize_batch / ScenePipeline), workers then only read files.",
+                      RuntimeWarning, stacklevel=3)
 
 
 class ToTensor:
@@ -45,6 +71,7 @@ class Voxelization:
 
     def __call__(self, sample):
         pts, labels = sample
+        _check_worker_context()
         g = Vox._voxelize_single(pts, labels, self.keep_labels, self.vxg_size, self.vox_size,
                                  want_density=True, want_gt=True, want_occ=False)
         # vox-point-density, vox-tower-prob : [1, nz, nx, ny] float64 numpy, like the reference

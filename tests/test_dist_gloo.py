@@ -89,3 +89,85 @@ def test_flat_gradient_exchange_without_group_is_a_no_op():
     p = torch.nn.Parameter(torch.ones(()))
     p.grad = torch.full((), 2.0)
     assert sna.allreduce_flat_grads([p]) == 0 and float(p.grad) == 2.0
+
+
+# --------------------------------------------------------------------------- bench.py --gpus N: the rank launcher
+def _load_launch():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_sn_launch_t", os.path.join(root, "scene-net_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+_RANK_SCRIPT = """
+import os, sys, json
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([float(os.environ["RANK"]) + 1.0])
+dist.all_reduce(t)
+with open(sys.argv[1] + "." + os.environ["RANK"], "w") as f:
+    json.dump({"rank": int(os.environ["RANK"]), "local": int(os.environ["LOCAL_RANK"]),
+               "world": dist.get_world_size(), "sum": float(t), "addr": os.environ["MASTER_ADDR"]}, f)
+dist.destroy_process_group()
+"""
+
+
+def test_launcher_starts_one_rank_per_device_over_gloo(tmp_path):
+    """launch_ranks sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like torch.distributed.run and the ranks can form a
+    process group with them (what `bench.py --gpus N` relies on)."""
+    import json
+    launch, _ = _load_launch()
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rc = launch.launch_ranks(2, str(script), [str(tmp_path / "out")], timeout_s=120)
+    assert rc == 0
+    got = [json.load(open(tmp_path / f"out.{r}")) for r in range(2)]
+    for r, g in enumerate(got):
+        assert g == {"rank": r, "local": r, "world": 2, "sum": 3.0, "addr": "127.0.0.1"}
+
+
+def test_launcher_reports_a_failed_rank_and_stops_the_rest(tmp_path):
+    import time as _t
+    launch, _ = _load_launch()
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(5)\ntime.sleep(120)\n")
+    t0 = _t.monotonic()
+    rc = launch.launch_ranks(2, str(script), [], timeout_s=100)
+    assert rc == 5 and _t.monotonic() - t0 < 60   # rank 0 was terminated, not waited for
+
+
+def test_launcher_module_is_stdlib_only():
+    """the launching parent must not import torch (or anything that could initialise the device)"""
+    import subprocess
+    import sys
+    _, root = _load_launch()
+    code = ("import importlib.util, sys; s = importlib.util.spec_from_file_location('l', sys.argv[1]); "
+            "m = importlib.util.module_from_spec(s); s.loader.exec_module(m); "
+            "assert 'torch' not in sys.modules and 'numpy' not in sys.modules; print(m.under_launcher({}))")
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(root, "scene-net_amd", "launch.py")],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "False", out.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher above it starts 2 ranks itself.  Without a HIP device every rank
+    stops at the device check (exit 3) -- and says which device it wanted, which shows two ranks ran with LOCAL_RANK
+    0 and 1.  A --gpus / WORLD_SIZE mismatch is refused (exit 2)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-side check of the launcher's refusal paths")
+    _, root = _load_launch()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, out.stderr[-400:]
+    assert "rank 0 needs HIP device 0" in out.stderr and "rank 1 needs HIP device 1" in out.stderr
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr

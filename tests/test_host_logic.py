@@ -252,3 +252,26 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_device_mismatch_is_refused_before_any_launch():
+    """a C-ABI call takes raw pointers and one stream; operands on different devices must be refused."""
+    from types import SimpleNamespace as NS
+    import scene_net_amd as sna
+    a = NS(is_cuda=True, device=torch.device("cuda:0"))
+    b = NS(is_cuda=True, device=torch.device("cuda:1"))
+    assert sna._hip._common_device([a, None, a]) == torch.device("cuda:0")
+    assert sna._hip._common_device([None, torch.zeros(1)]) is None   # CPU tensors: _ptr's own message
+    with pytest.raises(sna.HipLibraryError, match="different devices"):
+        sna._hip._common_device([a, b])
+    # every tensor-taking wrapper is guarded
+    for name in ("conv_bank", "conv_fused", "forward_auto", "geneo_bank", "voxel_occupancy_fused", "voxel_scatter",
+                 "conv_corr", "loss_forward", "loss_backward", "gather_points"):
+        assert hasattr(getattr(sna._hip, name), "__wrapped__"), name
+
+
+def test_voxelization_in_a_badly_forked_worker_says_what_to_do(monkeypatch):
+    import scene_net_amd as sna
+    monkeypatch.setattr(torch.cuda, "_is_in_bad_fork", lambda: True)
+    with pytest.raises(sna.HipLibraryError, match="spawn"):
+        sna.Voxelization([15], vxg_size=(8, 8, 8))((np.zeros((4, 3)), np.zeros(4)))
