@@ -12,7 +12,7 @@ CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(SRC) -Wall
 # voxel.hip reproduces numpy's fp64 rounding sequence: never contract a*b+c
 FLAGS_voxel := -ffp-contract=off
 
-SOURCES := cabi bank voxel conv conv_i8 conv_lin backward corr loss
+SOURCES := cabi bank voxel conv conv_i8 conv_i8s conv_lin backward corr loss
 OBJS    := $(SOURCES:%=$(OBJDIR)/%.o)
 
 all: $(OUT)/libscenenet_hip.so

@@ -67,10 +67,16 @@ const char* sn_last_error(void);
 /* Number of gfx950 devices visible (0 when none); never throws. */
 int sn_device_count(void);
 
-/* Process-wide options (default 0).
- *   "conv_skip_empty_tiles": sn_conv_bank on SN_OCC8 input skips the MFMA steps of workgroup tiles whose halo holds
- *       no set voxel (their response is exactly 0 for every kernel).  Output unchanged; run time becomes data
- *       dependent, so benchmarks quote it separately from the dense figure. */
+/* Process-wide options.
+ *   "conv_skip_empty_tiles" (default 0): sn_conv_bank on SN_OCC8 input skips the MFMA steps of workgroup tiles whose
+ *       halo holds no set voxel (their response is exactly 0 for every kernel).  Output unchanged; run time becomes
+ *       data dependent, so benchmarks quote it separately from the dense figure.
+ *   "conv_i8_tolerance_ppb" (default 90000 = 9e-5): the int8 kernels (sn_conv_bank / sn_conv_fused / sn_forward_auto on
+ *       binary occupancy) quantise the weights to 24-bit fixed point and compute, on the device, the exact worst case
+ *       of the resulting activation error over all binary inputs.  A bank whose bound exceeds value * 1e-9 is computed
+ *       by the fp32 kernel instead (decided on the device, no host synchronisation).  0 switches the guard off.
+ *   "conv_i8_legacy" (default 0): 1 = sn_conv_bank uses the four-copy int8 kernel (conv_i8.hip) for every shape
+ *       instead of the stride-4 kernel (conv_i8s.hip) it prefers for ky = 9 (A/B timing, parity tests of both). */
 int sn_set_option(const char* name, int value);
 int sn_get_option(const char* name);
 

@@ -1,6 +1,7 @@
 // C-ABI housekeeping: version, last-error text, device probe.
 #include "common.h"
 #include <cstring>
+#include <cstdlib>
 
 #include <atomic>
 #include <mutex>
@@ -13,11 +14,46 @@ char* error_buffer() {
 }
 static std::atomic<int> g_skip_empty{0};
 int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
+static std::atomic<int> g_i8_legacy{0};
+int option_conv_i8_legacy() { return g_i8_legacy.load(std::memory_order_relaxed); }
 
-static thread_local Gate g_gate{nullptr, 0};
+static thread_local Gate g_gate{{nullptr, nullptr, nullptr}, {0, 0, 0}};
 Gate current_gate() { return g_gate; }
-GateScope::GateScope(const int32_t* ptr, int want) { g_gate = Gate{ptr, want}; }
-GateScope::~GateScope() { g_gate = Gate{nullptr, 0}; }
+GateScope::GateScope(const int32_t* ptr, int want) : slot_(-1) {
+    for (int i = 0; i < kGateDepth; ++i)
+        if (!g_gate.ptr[i]) { slot_ = i; break; }
+    if (slot_ < 0) abort();
+    g_gate.ptr[slot_] = ptr;
+    g_gate.want[slot_] = want;
+}
+GateScope::~GateScope() {
+    g_gate.ptr[slot_] = nullptr;
+    g_gate.want[slot_] = 0;
+}
+
+// tolerance of the int8 kernels' quantisation guard, in units of 1e-9 (default 90 000 = 9e-5: the 1e-4 parity bar
+// less the fp32 roundings of the recombination)
+static std::atomic<int> g_i8_tol_ppb{90000};
+float option_conv_i8_tolerance() { return 1e-9f * (float)g_i8_tol_ppb.load(std::memory_order_relaxed); }
+
+int32_t* device_flag_slot() {
+    constexpr int kRing = 1024, kMaxDev = 16;
+    static std::mutex mu;
+    static int32_t* ring[kMaxDev] = {nullptr};
+    static unsigned next[kMaxDev] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ring[dev]) {
+        if (hipMalloc((void**)&ring[dev], kRing * sizeof(int32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            ring[dev] = nullptr;
+            return nullptr;
+        }
+        (void)hipMemset(ring[dev], 0, kRing * sizeof(int32_t));
+    }
+    return ring[dev] + (next[dev]++ % kRing);
+}
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
     static std::mutex mu;
@@ -40,11 +76,22 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_skip_empty.store(value ? 1 : 0, std::memory_order_relaxed);
         return SN_OK;
     }
+    if (strcmp(name, "conv_i8_tolerance_ppb") == 0) {
+        if (value < 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: conv_i8_tolerance_ppb must be >= 0");
+        sn::g_i8_tol_ppb.store(value, std::memory_order_relaxed);
+        return SN_OK;
+    }
+    if (strcmp(name, "conv_i8_legacy") == 0) {
+        sn::g_i8_legacy.store(value ? 1 : 0, std::memory_order_relaxed);
+        return SN_OK;
+    }
     return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: unknown option '%s'", name);
 }
 
 extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_skip_empty_tiles") == 0) return sn::option_conv_skip_empty_tiles();
+    if (name && strcmp(name, "conv_i8_tolerance_ppb") == 0) return sn::g_i8_tol_ppb.load(std::memory_order_relaxed);
+    if (name && strcmp(name, "conv_i8_legacy") == 0) return sn::option_conv_i8_legacy();
     return -1;
 }
 

@@ -49,8 +49,7 @@ struct ConvShape {
     int T4;              // tap steps of 4, rounded up to even (ping-pong unroll)
     int Gtot, g0;        // this launch handles kernels g0 .. g0+G-1 of a bank of Gtot (act channel stride)
     int head;            // bit 0: add the partial sum already in `out`; bit 1: apply relu(tanh) (else store raw)
-    const int32_t* gate; // run only if null or *gate == gate_want (common.h: Gate)
-    int gate_want;
+    sn::Gate gate;       // run only if every condition holds (common.h: Gate)
 };
 
 template <typename T>
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void conv_bank_kernel(const XT* __restric
                                                              const float* __restrict__ bank,
                                                              const float* __restrict__ lambdas, ConvShape s,
                                                              OT* __restrict__ act, OT* __restrict__ out) {
-    if (s.gate && *s.gate != s.gate_want) return;
+    if (!s.gate.pass()) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -402,6 +401,9 @@ namespace sn {
 int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
                 int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
                 hipStream_t stream);  // conv_i8.hip
+int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
+                 int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                 hipStream_t stream);  // conv_i8s.hip
 int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
                     int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
                     sn_stream_t stream);
@@ -444,6 +446,13 @@ int sn::conv_bank_group(const void* x, int x_dtype, const float* bank, const flo
         // binary occupancy bytes: int8 matrix cores (exact integer accumulation of 24-bit fixed-point weights)
         const char* no_i8 = getenv("SN_CONV_NO_I8");
         if (!(no_i8 && no_i8[0] == '1')) {
+            // ky = 9: the stride-4 kernel (one halo copy, 12 MFMA steps); everything else: the four-copy kernel
+            const char* legacy = getenv("SN_CONV_I8_LEGACY");
+            if (!sn::option_conv_i8_legacy() && !(legacy && legacy[0] == '1')) {
+                const int rs = sn::conv_occ_i8s((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky,
+                                                act, out, out_dtype, sn::as_stream(stream));
+                if (rs <= 0) return rs;
+            }
             const int rc = sn::conv_occ_i8((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky,
                                            act, out, out_dtype, sn::as_stream(stream));
             if (rc <= 0) return rc;
@@ -454,7 +463,7 @@ int sn::conv_bank_group(const void* x, int x_dtype, const float* bank, const flo
     ConvShape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
-    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
+    s.gate = sn::current_gate();
     s.T4 = (((kz * kx * ky + 3) / 4) + 1) & ~1;
     s.nyt = (Y + TY - 1) / TY;
     const int cus = num_cus();

@@ -3,12 +3,15 @@
 // Same contraction as csrc/conv.hip (SceneNet.forward, core/models/SCENE_Net.py:322-339) specialised to what
 // the network is actually fed: ToFullDense(Voxelization(points)) is {0,1} (torch_transforms.py:33-34), exact
 // in int8.  The fp32 GENEO weights are turned into 24-bit fixed point per kernel,
-//     Q[g][t] = rint(W[g][t] * 2^F_g),  2^(22-F_g) >= max_t |W[g][t]|   (|Q| <= 2^22)
-// and split into three balanced base-256 digits Q = d0 + 256 d1 + 65536 d2, d_i in [-128, 127].  Three
+//     Q[g][t] = rint(W[g][t] * S_g) (in fp64),  S_g = 8355711 / max_t |W[g][t]|   (|Q| <= 8355711 = 127 * 65793,
+// the whole range of three balanced base-256 digits)
+// and split into the digits Q = d0 + 256 d1 + 65536 d2, d_i in [-128, 127].  Three
 // v_mfma_i32_16x16x64_i8 per 64 taps accumulate S_i = sum_t d_i[g][t] x[v+t] EXACTLY in int32 (order
-// independent, bit-reproducible); the epilogue recombines (S2*65536 + S1*256 + S0) * 2^-F_g in fp32.
-// Error vs the fp64 reference: the weight quantisation only, <= 2^-23 * 2^ceil(log2 max|W_g|) per tap
-// (same order as an fp32 fmaf chain), plus one fp32 rounding of the sum.
+// independent, bit-reproducible); the epilogue recombines (S2*65536 + S1*256 + S0) * (max|W_g| / 8355711) in fp32.
+// Error vs the fp64 reference: the weight quantisation only, <= 0.5 * max|W_g| / 8355711 = 6e-8 max|W_g| per tap,
+// plus the fp32 roundings of the recombination.  The prologue computes the exact worst case over all binary inputs
+// (max of the summed positive and the summed negative errors, per kernel and lambda-weighted); a bank whose bound
+// exceeds the tolerance (sn_set_option "conv_i8_tolerance_ppb") is handed to the fp32 kernel: *route = 1.
 //
 // GEMM view per 16-voxel strip along y: M = 16 kernels (A = digit bytes), N = 16 voxels (B = occupancy
 // bytes), K = 64 "slots" per MFMA.  A lane (q = l>>4, n = l&15) supplies 16 bytes = 4 dwords per MFMA; each
@@ -28,8 +31,13 @@ namespace {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
-// torch.relu keeps NaN (fmaxf(NaN, 0) would return 0)
-__device__ __forceinline__ float relu_nan(float v) { return (v > 0.0f || v != v) ? v : 0.0f; }
+// relu(tanh(v)): 0 for v <= 0, else 1 - 2 / (exp(2v) + 1) on the hardware exp / rcp (abs. error ~2e-7, inside the 1e-4
+// bar; same form as conv_lin.hip and conv_i8s.hip).  NaN stays NaN like torch.relu(torch.tanh(.)); +inf -> 1.
+__device__ __forceinline__ float relu_tanh(float v) {
+    if (v != v) return v;
+    if (!(v > 0.0f)) return 0.0f;
+    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
+}
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
@@ -53,8 +61,9 @@ struct Shape {
     int CB;         // bytes between the shifted copies
     int Gtot, g0, head;  // kernel group of a larger bank: act channel stride/offset; head bits (see conv.hip)
     int XPAD;       // unused halo rows appended to every z plane (bank placement, see conv_occ_i8)
-    const int32_t* gate;  // run only if null or *gate == gate_want (common.h: Gate)
-    int gate_want;
+    sn::Gate gate;       // run only if every condition holds (common.h: Gate)
+    int32_t* route; // out: 1 = quantisation bound exceeded (the gated fp32 launch behind takes over), 0 = done here
+    float tol;      // bound on the worst-case activation error allowed here (<= 0: no check)
     int perm;       // tile order multiplier, coprime to ntiles
     int skip_empty; // opt-in: skip the MFMA steps of halo tiles without a set voxel (result is exactly 0)
     int dbg;        // timing experiments only (SN_CONV_I8_DBG): 1 = no epilogue, 2 = no halo refill, 4 = no barrier,
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                                                                const float* __restrict__ lambdas, Shape s,
                                                                int* __restrict__ ticket, OT* __restrict__ act,
                                                                OT* __restrict__ out) {
-    if (s.gate && *s.gate != s.gate_want) return;
+    if (!s.gate.pass()) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -256,9 +265,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     // LDS carve-up
     uint4* Wd = reinterpret_cast<uint4*>(lds);                            // [KT][3][64] x 16 B
     int4* coff = reinterpret_cast<int4*>(lds + (size_t)KT * 3 * 64 * 16); // [KT][4] x 16 B
-    float* scale = reinterpret_cast<float*>(coff + KT * 4);               // [16]   2^-F_g
-    int* shiftF = reinterpret_cast<int*>(scale + 16);                     // [16]   F_g
-    int* wseen = shiftF + 16;                                             // [8]    per wave: halo tile has a set voxel
+    float* scale = reinterpret_cast<float*>(coff + KT * 4);               // [16]   max|W_g| / 8355711
+    double* Sq = reinterpret_cast<double*>(scale + 16);                   // [16]   8355711 / max|W_g|
+    double* bnd = Sq + 16;                                                // [16]   worst-case quantisation error
+    int* wseen = reinterpret_cast<int*>(bnd + 16);                        // [8]    per wave: halo tile has a set voxel
     int* tnext = wseen + 8;                                               // [1]    dynamic scheduling: next tile
     uint8_t* xs = reinterpret_cast<uint8_t*>(wseen + 16);                 // 4 copies x CB bytes
     uint32_t* stage = reinterpret_cast<uint32_t*>(xs + 4 * (size_t)s.CB); // kStage: [rows][YPB/4] (+1) raw dwords
@@ -302,18 +312,46 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             const float u = __shfl_xor(m, o, 64);
             m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
         }
+        const double S = (m > 0.0f) ? 8355711.0 / (double)m : 0.0;   // NaN: comparison false, scale = NaN below
+        double ep = 0.0, en = 0.0;
+        if (g < s.G && m > 0.0f)
+            for (int t = lane; t < ntaps; t += 64) {
+                const double w = (double)bank_s[g * ntaps + t];
+                const double e = (double)__double2int_rn(w * S) * ((double)m / 8355711.0) - w;
+                ep += e > 0.0 ? e : 0.0;
+                en += e < 0.0 ? -e : 0.0;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ep += __shfl_xor(ep, o, 64);
+            en += __shfl_xor(en, o, 64);
+        }
         if (lane == 0) {
-            int e = 0;
-            if (m > 0.0f) (void)frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)  ->  m <= 2^e
-            const int F = 22 - e;
-            shiftF[g] = F;
+            Sq[g] = S;
             // fixed point cannot carry a NaN / inf weight: such a kernel's whole response is NaN, as it is in
             // conv3d (0 * NaN = NaN at every voxel)
-            scale[g] = (m != m) ? m : ldexpf(1.0f, -F);
+            scale[g] = (m != m) ? m : (float)((double)m / 8355711.0);
+            bnd[g] = ep > en ? ep : en;
         }
     }
     lds_barrier();
     SN_T(2);
+    // route: every workgroup takes the same decision from the same numbers
+    if (s.tol > 0.0f) {
+        double worst = 0.0, mixed = 0.0;
+        for (int g = 0; g < s.G; ++g) {
+            worst = bnd[g] > worst ? bnd[g] : worst;
+            if (out) mixed += fabs((double)lambdas[g]) * bnd[g];   // tanh and relu are 1-Lipschitz
+        }
+        const bool exceeded = (act && worst > (double)s.tol) || (out && mixed > (double)s.tol);
+        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
+        if (exceeded) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
+            return;
+        }
+    } else if (blockIdx.x == 0 && tid == 0 && s.route) {
+        *s.route = 0;
+    }
     // ---- digit table Wd[s][d][l] (16 bytes: slot (q, p)) and chunk offset table coff[s][q] (4 dwords j)
     const int nchunks = s.R * s.C;
     for (int i = tid; i < KT * 64; i += kThreads) {  // one thread quantises 16 taps once and emits all 3 digit rows
@@ -321,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         const int g = l & 15, qq = l >> 4;
         uint32_t w0[4] = {0u, 0u, 0u, 0u}, w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
         if (g < s.G && st < s.KS) {
-            const float twoF = ldexpf(1.0f, shiftF[g]);  // exact power of two: wv * 2^F is exact
+            const double S = Sq[g];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int li = slot_index<YPB>(st, qq, j);
@@ -331,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     for (int b = 0; b < 4; ++b) {
                         const int dy = 4 * c + b;
                         if (dy < s.ky) {
-                            int Q = __float2int_rn(bank_s[g * ntaps + rho * s.ky + dy] * twoF);
+                            int Q = __double2int_rn((double)bank_s[g * ntaps + rho * s.ky + dy] * S);
                             const int d0 = ((Q + 128) & 255) - 128;
                             Q = (Q - d0) >> 8;
                             const int d1 = ((Q + 128) & 255) - 128;
@@ -369,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     for (int r = 0; r < 4; ++r) {
         const int g = 4 * q + r;
         sc[r] = scale[g];
-        if (out) lam[r] = (g < s.G) ? lambdas[g] * sc[r] : 0.0f;  // the 2^-F_g rescale rides on lambda (exact)
+        if (out) lam[r] = (g < s.G) ? lambdas[g] * sc[r] : 0.0f;  // the rescale rides on lambda
     }
 
     const int half_tx = s.TX >> 1;
@@ -566,8 +604,8 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                     p = fmaf(lam[1], val[v][1], p);
                     p = fmaf(lam[2], val[v][2], p);
                     p = fmaf(lam[3], val[v][3], p);
+                    p += __shfl_xor(p, 32, 64);   // (q, q+2) then (q, q+1): the association conv_i8s.hip's swaps give
                     p += __shfl_xor(p, 16, 64);
-                    p += __shfl_xor(p, 32, 64);
                     sums[v] = p;
                 }
 #pragma unroll
@@ -580,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                         OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
                         float t = sv;
                         if (s.head & 1) t += (float)load_now(o);
-                        *o = (OT)((s.head & 2) ? relu_nan(tanhf(t)) : t);
+                        *o = (OT)((s.head & 2) ? relu_tanh(t) : t);
                     }
                 }
             }
@@ -617,7 +655,7 @@ size_t lds_bytes(const Shape& s, int ypb, bool stage) {
     const size_t rows = (size_t)(s.TZ + s.kz - 1) * (s.TX + s.kx - 1 + s.XPAD);
     const size_t halo = 4 * (size_t)s.CB + (stage ? rows * ypb + 16 : 0);
     const size_t staged_bank = ((size_t)s.G * s.kz * s.kx * s.ky + 1) * sizeof(float);  // aliases the halo area (+ 1 pad)
-    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 4 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
+    return KT * 3 * 64 * 16 + KT * 4 * 16 + 16 * 4 + 16 * 8 + 16 * 8 + 16 * 4 + (halo > staged_bank ? halo : staged_bank);
 }
 
 int num_cus() {
@@ -637,22 +675,9 @@ int num_cus() {
 
 namespace sn {
 
-// one int per launch out of a device-resident ring (see the launch below)
-static int* ticket_slot() {
-    constexpr int kRing = 1024, kMaxDev = 16;
-    static std::mutex mu;
-    static int* ring[kMaxDev] = {nullptr};
-    static unsigned next[kMaxDev] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ring[dev] && hipMalloc((void**)&ring[dev], kRing * sizeof(int)) != hipSuccess) {
-        (void)hipGetLastError();
-        ring[dev] = nullptr;
-        return nullptr;
-    }
-    return ring[dev] + (next[dev]++ % kRing);
-}
+int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
+                    int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                    sn_stream_t stream);   // conv.hip
 
 // returns SN_OK, an error, or 1 when this shape is not served by the int8 kernel (caller falls back to fp32)
 int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
@@ -661,7 +686,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     Shape s;
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx; s.ky = ky;
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
-    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
+    s.gate = sn::current_gate();
     s.C = (ky + 3) / 4;
     if (s.C > kMaxC) return 1;
     s.R = kz * kx;
@@ -720,11 +745,17 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
         // may be in flight before a slot is reused.
         int* ticket = nullptr;
         if (s.skip_empty && s.ntiles > grid) {
-            ticket = ticket_slot();
+            ticket = sn::device_flag_slot();
             if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), stream) != hipSuccess) {
                 (void)hipGetLastError();
                 ticket = nullptr;  // static order still gives the right answer
             }
+        }
+        s.tol = sn::option_conv_i8_tolerance();
+        s.route = nullptr;
+        if (s.tol > 0.0f) {
+            s.route = sn::device_flag_slot();
+            if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
         }
 #define SN_LAUNCH_I8(OT, YPBV, STG)                                                                              \
     do {                                                                                                         \
@@ -740,7 +771,13 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
             if (stage) SN_LAUNCH_I8(double, 80, true); else SN_LAUNCH_I8(double, 96, false);
         }
 #undef SN_LAUNCH_I8
-        return check_launch("sn_conv_bank(i8)");
+        if (int rc = check_launch("sn_conv_bank(i8)")) return rc;
+        if (s.route) {   // the same launch on the fp32 matrix pipe, enqueued behind: runs only if the guard sent it there
+            sn::GateScope guard(s.route, 1);
+            return sn::conv_bank_group(x, SN_U8, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky, act, out,
+                                       out_dtype, reinterpret_cast<sn_stream_t>(stream));
+        }
+        return SN_OK;
     }
     return 1;
 }

@@ -1,0 +1,872 @@
+// K3'' -- GENEO bank convolution for BINARY OCCUPANCY on the int8 matrix cores, ky = 9: stride-4 voxel map.
+//
+// Same contraction and the same fixed-point arithmetic as csrc/conv_i8.hip (SceneNet.forward,
+// core/models/SCENE_Net.py:322-339 on ToFullDense(Voxelization(points)), torch_transforms.py:33-34): per kernel
+// 24-bit fixed-point weights in three balanced base-256 digits, three v_mfma_i32_16x16x64_i8 per 64 K-slots, exact
+// int32 sums, fp32 recombination and head.  What differs is how the B operand (the im2col of the occupancy bytes)
+// is fed, which decides both the number of MFMAs and everything around them:
+//
+//   * lane (q, n) of accumulator tile (h, r) is voxel  y = y0 + 4 n + r  of x-row h  (r = 0..3: four "residue"
+//     tiles cover 64 consecutive y).  All 16 lanes of a tile then have the SAME byte alignment, and the 9-tap
+//     window of a kernel row (dz, dx) is bytes r .. r+8 of the three aligned halo dwords D0 D1 D2 = dwords n, n+1,
+//     n+2 of the halo row -- shared by the four residues.  The operand dword for taps 4c..4c+3 is
+//     v_alignbyte(D[c+1], D[c], r): ONE halo copy in LDS (1 byte per voxel) instead of four byte-shifted ones, and
+//     a quarter of the LDS reads;
+//   * tap 8 of a row is byte r of D2.  The tap-8 bytes of FOUR kernel rows are packed into one K dword by a 4x4
+//     byte transpose of their D2's (8 v_perm_b32 give the dwords of all four residues), so a kernel row costs
+//     2 1/4 K-dwords, not 3:  81 rows -> 183 dwords -> 12 MFMA steps of 16 dwords instead of 16 (-25 % MFMAs);
+//   * the 65 KiB the shifted copies took hold a RING of three halo buffers filled by LDS-DMA two tiles ahead.
+//     A wave moves from tile to tile on two LDS counters per buffer (landed / done) -- no workgroup barrier in the
+//     tile loop -- so the two waves of a SIMD can run half a round apart for the whole launch: one wave's epilogue
+//     and DMA issue overlap its partner's MFMAs (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+//
+// Quantisation (per kernel g): S_g = 8355711 / max|W_g| (8355711 = 127 * 65793, the largest magnitude three
+// balanced digits hold), Q = rint(W * S_g) in fp64, act = S * (max|W_g| / 8355711).  The prologue also computes the
+// exact worst case of the quantisation error over all binary inputs, max(sum of positive errors, sum of negative
+// errors), per kernel and lambda-weighted; a bank whose bound exceeds the tolerance is not run here: every
+// workgroup returns and *route = 1 sends the launch to the fp32 kernel enqueued behind this one (conv.hip).
+#include "common.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+// relu(tanh(v)): 0 for v <= 0, else 1 - 2 / (exp(2v) + 1) on the hardware exp / rcp (abs. error ~2e-7, inside the 1e-4
+// bar; same form as conv_lin.hip).  NaN stays NaN like torch.relu(torch.tanh(.)); +inf -> 1.
+__device__ __forceinline__ float relu_tanh(float v) {
+    if (v != v) return v;
+    if (!(v > 0.0f)) return 0.0f;
+    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
+}
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int TY = 64;          // y extent of a workgroup tile: 16 lanes x 4 residues
+constexpr int NV = 8;           // accumulator tiles per wave round: 2 x-rows x 4 residues
+constexpr int DW = 24;          // halo row stride in dwords (96 bytes = 16 + 64 + 16): rows 2 (mod 4) apart differ by 16 banks
+constexpr int PYA = 16;         // halo origin y0 - 16: every 16-byte piece of a row is wholly inside or outside the grid
+constexpr int D0 = PYA / 4 - 1; // dword of a row that holds tap 0 of lane 0, residue 0 (py = 4)
+constexpr int kRowPieces = DW / 4;             // 16-byte pieces per halo row
+constexpr int kDmaRows = 64 / kRowPieces;      // halo rows one LDS-DMA wave-instruction moves (10; 4 lanes idle)
+constexpr int kNB = 3;          // halo ring
+constexpr int kMaxRQ = 24;      // kernel rows per lane group (kz * kx <= 96)
+constexpr int kMaxLds = 160 * 1024;
+constexpr int kSpinMax = 1 << 22;
+constexpr double kQMax = 8355711.0;
+
+// which kernel rows (dz, dx) lane group q carries, in what order (host-built: plan_rows)
+struct RowPlan {
+    short halo[4][kMaxRQ];   // halo row index dz * XP + dx (pad entries: any valid row)
+    short tap[4][kMaxRQ];    // kernel row index dz * kx + dx, -1 = pad (zero weights)
+};
+
+struct Shape {
+    int B, Z, X, Y, G;
+    int kz, kx;
+    int TZ, TX, nzt, nxt, nyt, ntiles;
+    int XP, ZP;            // halo rows per z plane (incl. pad), halo planes
+    int RQ, NP, NT, ODD;   // rows per lane group; pair steps; tap-8 quads; RQ odd (last row's chunks in the tail)
+    int NTS, KS;           // tail steps, all steps
+    int Gtot, g0, head;    // kernel group of a larger bank (see conv.hip)
+    sn::Gate gate;
+    int32_t* route;        // out: 1 = quantisation bound exceeded, fp32 kernel takes the launch; 0 = done here
+    float tol;             // bound on the worst-case activation error allowed on the int8 path (<= 0: no check)
+    int stagger;           // s_sleep units (64 clocks) waves 4-7 wait once before their first round
+    int dbg;
+    RowPlan plan;
+};
+
+struct TileCoord {
+    int b, z0, x0, y0;
+};
+
+__device__ __forceinline__ TileCoord tile_coord(const Shape& s, int tile) {
+    TileCoord c;
+    c.y0 = (tile % s.nyt) * TY; tile /= s.nyt;
+    c.x0 = (tile % s.nxt) * s.TX; tile /= s.nxt;
+    c.z0 = (tile % s.nzt) * s.TZ; tile /= s.nzt;
+    c.b = tile;
+    return c;
+}
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero_word_s[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ float load_now(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ double load_now(const double* p) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// workgroup barrier that orders LDS traffic only: LDS-DMA in flight stays in flight
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// LDS-DMA of one tile's raw halo rows into a ring buffer, 16 bytes per lane: one wave-instruction moves TEN whole halo
+// rows (60 lanes; lane -> (row lane / 6, piece lane % 6) is the same for every instruction), instructions are dealt
+// round-robin over the waves, and from one to the next every lane advances by 80 rows: the row split r -> (zz, xx) is
+// one add and a conditional wrap, no division.  [measured] item = linear dword index, 4 bytes per lane: 12 instructions
+// and 1.9 us per wave and tile; this form: 4 instructions.  Pieces outside the grid are fetched from a zero block (with
+// Y % 16 == 0 and the origin at y0 - 16 a piece never straddles the grid's edge).  Inline asm: the builtin's LDS write
+// would make hipcc wait vmcnt(0) before every later ds_read (see conv_i8.hip); arrival is tracked by this wave's own
+// vmcnt(0) + the `landed` counter.
+struct DmaLane {
+    int rl, i;        // row within an instruction (kDmaRows = idle lane), 16-byte piece within the row
+    int zz0, xx0;     // (zz, xx) of this lane's row in the wave's first instruction
+    int dzz, dxx;     // advance per instruction: kDmaRows * kWaves rows = dzz planes + dxx rows
+};
+__device__ __forceinline__ DmaLane dma_lane(const Shape& s, int wave, int lane) {
+    DmaLane d;
+    d.rl = lane / kRowPieces;
+    d.i = lane - d.rl * kRowPieces;
+    const int r0 = kDmaRows * wave + d.rl;
+    d.zz0 = r0 / s.XP;
+    d.xx0 = r0 - d.zz0 * s.XP;
+    d.dzz = (kDmaRows * kWaves) / s.XP;
+    d.dxx = kDmaRows * kWaves - d.dzz * s.XP;
+    return d;
+}
+__device__ __forceinline__ void halo_dma_issue(uint32_t* __restrict__ buf, const uint8_t* __restrict__ x,
+                                               const Shape& s, const TileCoord& c, const DmaLane& d, int wave) {
+    const int hrows = s.ZP * s.XP;
+    const uint8_t* tb = x + (size_t)c.b * s.Z * s.X * s.Y;
+    const int oz = c.z0 - (s.kz - 1) / 2, ox = c.x0 - (s.kx - 1) / 2;
+    const int gy = c.y0 - PYA + 16 * d.i;
+    const bool oky = d.rl < kDmaRows && (unsigned)gy < (unsigned)s.Y;
+    int zz = d.zz0, xx = d.xx0;
+    for (int r0 = kDmaRows * wave; r0 < hrows; r0 += kDmaRows * kWaves) {
+        const int gz = oz + zz, gx = ox + xx;
+        const bool ok = oky && (unsigned)gz < (unsigned)s.Z && (unsigned)gx < (unsigned)s.X;
+        const void* src = ok ? static_cast<const void*>(tb + ((gz * s.X + gx) * s.Y + gy))
+                             : static_cast<const void*>(g_zero_word_s);
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(buf + r0 * DW);
+        const uint32_t lds_uni = __builtin_amdgcn_readfirstlane(lds_base);
+        // idle lanes and rows past the end of the buffer stay out (EXEC): their piece would land in the next ring slot
+        if (d.rl < kDmaRows && r0 + d.rl < hrows) {
+            uint32_t m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "s"(lds_uni), "v"(src) : "memory");
+        }
+        zz += d.dzz;
+        xx += d.dxx;
+        const bool w = xx >= s.XP;   // dxx < XP: one wrap at most
+        xx -= w ? s.XP : 0;
+        zz += w;
+    }
+}
+
+// LDS counters between the waves of the workgroup (monotonic; one add per wave per event)
+__device__ __forceinline__ void wave_signal(int* c, int lane) {
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool wave_wait(const int* c, int expect) {
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(c)) < expect) {
+        if (++spins > kSpinMax) return false;   // cannot happen (every wave reaches its signals); never hang the GPU
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+// 4x4 byte transpose: o[r] = (a.byte r, b.byte r, c.byte r, d.byte r)
+__device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t (&o)[4]) {
+    const uint32_t p0 = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a0 b0 a1 b1
+    const uint32_t p1 = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a2 b2 a3 b3
+    const uint32_t q0 = __builtin_amdgcn_perm(d, c, 0x05010400u);   // c0 d0 c1 d1
+    const uint32_t q1 = __builtin_amdgcn_perm(d, c, 0x07030602u);   // c2 d2 c3 d3
+    o[0] = __builtin_amdgcn_perm(q0, p0, 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(q0, p0, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(q1, p1, 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(q1, p1, 0x07060302u);
+}
+
+template <int R>
+__device__ __forceinline__ uint32_t window(uint32_t hi, uint32_t lo) {   // bytes R .. R+3 of (hi : lo)
+    if constexpr (R == 0) return lo;
+    else return __builtin_amdgcn_alignbyte(hi, lo, R);
+}
+
+#ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING OUT=build/timing OBJDIR=build/obj_timing; read by tools/i8s_timing.py
+__device__ unsigned long long g_i8s_t[1024 * 16];
+__device__ unsigned long long g_i8s_w[1024 * 8 * 8];   // [workgroup][wave][phase]: summed wall_clock64 ticks (10 ns)
+#define SN_ST(k) do { if (threadIdx.x == 0) g_i8s_t[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define SN_WT0() const unsigned long long t_ph0 = wall_clock64()
+#define SN_WT(k, t0) do { if (lane == 0) g_i8s_w[(blockIdx.x * 8 + wave) * 8 + (k)] += wall_clock64() - (t0); } while (0)
+#define SN_WNOW() wall_clock64()
+#else
+#define SN_ST(k) do {} while (0)
+#define SN_WT(k, t0) do { (void)(t0); } while (0)
+#define SN_WNOW() 0ull
+#endif
+
+// kNT >= 0: the step structure (pair steps, tap-8 quads, odd row) is known at compile time -- 9 x 9 kernel rows:
+// <10, 6, 1> --, which makes every tail slot's kind and the peeled end of the pair loop static (one code path: with the
+// run-time form hipcc keeps a second copy of the 96 accumulator registers across the join and spills); kNT < 0: taken
+// from the shape.
+template <typename OT, int kNP, int kNT, int kODD>
+__global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* __restrict__ x,
+                                                                const float* __restrict__ bank,
+                                                                const float* __restrict__ lambdas, Shape s,
+                                                                OT* __restrict__ act, OT* __restrict__ out) {
+    if (!s.gate.pass()) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    SN_ST(0);
+
+    const int NP = kNT >= 0 ? kNP : s.NP;
+    const int NT = kNT >= 0 ? kNT : s.NT;
+    const int ODD = kNT >= 0 ? kODD : s.ODD;
+    const int NTS = (NT + 2 * ODD + 3) / 4;
+    const int ntaps = s.kz * s.kx * 9;
+    const int hrows = s.ZP * s.XP;
+    const int hdw = hrows * DW;   // dwords per halo buffer
+    // LDS carve-up
+    uint4* Wd = reinterpret_cast<uint4*>(lds);                                   // [KS][3][64] x 16 B
+    int2* roff = reinterpret_cast<int2*>(Wd + (size_t)s.KS * 3 * 64);            // [NP][4]   byte offsets of rows A, B
+    int4* toff = reinterpret_cast<int4*>(roff + s.NP * 4);                       // [NT][4]   byte offsets of a quad's rows
+    int* oddoff = reinterpret_cast<int*>(toff + s.NT * 4);                       // [4]       byte offset of the odd row
+    float* scale = reinterpret_cast<float*>(oddoff + 4);                         // [16]   max|W_g| / 8355711
+    float* lamsc = scale + 16;                                                   // [16]   lambda_g * scale_g
+    double* Sq = reinterpret_cast<double*>(lamsc + 16);                          // [16]   8355711 / max|W_g|
+    double* bnd = Sq + 16;                                                       // [16]   worst-case error per kernel
+    int* landed = reinterpret_cast<int*>(bnd + 16);                              // [kNB]  waves whose DMA pieces are in
+    int* done = landed + 4;                                                      // [kNB]  waves finished with the buffer
+    int* flags = done + 4;                                                       // [4]    0: route, 1: a spin gave up
+    uint32_t* hbuf = reinterpret_cast<uint32_t*>(flags + 4);                     // [kNB][hdw] raw halo dwords
+    float* bank_s = reinterpret_cast<float*>(hbuf + (size_t)2 * hdw);            // [G][ntaps] (+1 pad), prologue only: over ring slot 2
+                                                                                 // (first filled during tile 0's rounds) and beyond
+
+#ifdef SN_CONV_TIMING
+    if (lane < 8) g_i8s_w[(blockIdx.x * 8 + wave) * 8 + lane] = 0;
+#endif
+    const int my_tiles = (int)blockIdx.x < s.ntiles ? (s.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (tid < 12) landed[tid] = 0;   // landed[0..3], done[0..3], flags[0..3]
+    {   // fp32 bank -> LDS, coalesced, one batch of loads; the first two tiles' halos are requested while those loads fly
+        // (the other way round the bank's loads queue behind 24 DMA pieces per wave: vmcnt retires in order) and
+        // travel while the tables are built
+        const int nb = s.G * ntaps;
+        constexpr int kB = 24;
+        for (int base = tid; base < nb; base += kThreads * kB) {
+            float v[kB];
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const int i = base + u * kThreads;
+                v[u] = bank[i < nb ? i : 0];
+            }
+            if (base == tid) {
+                const DmaLane dl = dma_lane(s, wave, lane);
+                if (my_tiles > 0) halo_dma_issue(hbuf, x, s, tile_coord(s, blockIdx.x), dl, wave);
+                if (my_tiles > 1) halo_dma_issue(hbuf + hdw, x, s, tile_coord(s, blockIdx.x + gridDim.x), dl, wave);
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const int i = base + u * kThreads;
+                bank_s[i < nb ? i : nb] = v[u];
+            }
+        }
+    }
+    lds_barrier();
+    SN_ST(1);
+    // ---- per kernel: max|W|, the fixed-point scale, and the exact worst case of the quantisation error
+    for (int g = wave; g < 16; g += kWaves) {
+        float m = 0.0f;
+        if (g < s.G)
+            for (int t = lane; t < ntaps; t += 64) {
+                const float a = fabsf(bank_s[g * ntaps + t]);
+                m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);   // NaN / inf poisons the kernel
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float u = __shfl_xor(m, o, 64);
+            m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
+        }
+        const double S = (m > 0.0f) ? kQMax / (double)m : 0.0;   // NaN: comparisons false -> S = 0, scale = NaN below
+        const double invS = (double)m / kQMax;   // Q * invS instead of Q / S: 2e-16 relative, nothing next to the errors summed
+        double ep = 0.0, en = 0.0;
+        if (g < s.G && m > 0.0f)
+            for (int t = lane; t < ntaps; t += 64) {
+                const double w = (double)bank_s[g * ntaps + t];
+                const double e = (double)__double2int_rn(w * S) * invS - w;
+                ep += e > 0.0 ? e : 0.0;
+                en += e < 0.0 ? -e : 0.0;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ep += __shfl_xor(ep, o, 64);
+            en += __shfl_xor(en, o, 64);
+        }
+        if (lane == 0) {
+            Sq[g] = S;
+            scale[g] = (m != m) ? m : (float)((double)m / kQMax);
+            bnd[g] = ep > en ? ep : en;
+        }
+    }
+    lds_barrier();
+    SN_ST(2);
+    // ---- route: all workgroups take the same decision from the same numbers
+    if (s.tol > 0.0f) {
+        double worst = 0.0, mixed = 0.0;
+        for (int g = 0; g < s.G; ++g) {
+            worst = bnd[g] > worst ? bnd[g] : worst;
+            if (out) mixed += fabs((double)lambdas[g]) * bnd[g];   // tanh and relu are 1-Lipschitz
+        }
+        const bool exceeded = (act && worst > (double)s.tol) || (out && mixed > (double)s.tol);
+        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
+        if (exceeded) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
+            return;
+        }
+    } else if (blockIdx.x == 0 && tid == 0 && s.route) {
+        *s.route = 0;
+    }
+    // ---- digit table Wd[st][d][l = (qq, g)]: 4 dwords j, slot (st, qq, j)
+    //   pair step st < NP:   j = 2 e + c  ->  taps 4c .. 4c+3 of row 2 st + e of lane group qq
+    //   tail step:           slot t = 4 (st - NP) + j:  t < NT: tap 8 of rows 4t .. 4t+3;  then (ODD) chunks 0, 1 of row RQ-1
+    for (int i = tid; i < s.KS * 64; i += kThreads) {
+        const int l = i & 63, st = i >> 6;
+        const int g = l & 15, qq = l >> 4;
+        uint32_t w0[4] = {0u, 0u, 0u, 0u}, w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+        if (g < s.G) {
+            const double S = Sq[g];
+            auto put = [&](int j, int b, int krow, int dy) {
+                if (krow < 0) return;
+                int Q = __double2int_rn((double)bank_s[g * ntaps + krow * 9 + dy] * S);
+                const int d0 = ((Q + 128) & 255) - 128;
+                Q = (Q - d0) >> 8;
+                const int d1 = ((Q + 128) & 255) - 128;
+                const int d2 = (Q - d1) >> 8;
+                w0[j] |= (uint32_t)(d0 & 255) << (8 * b);
+                w1[j] |= (uint32_t)(d1 & 255) << (8 * b);
+                w2[j] |= (uint32_t)(d2 & 255) << (8 * b);
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (st < s.NP) {
+                    const int krow = s.plan.tap[qq][2 * st + (j >> 1)];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) put(j, b, krow, 4 * (j & 1) + b);
+                } else {
+                    const int t = 4 * (st - s.NP) + j;
+                    if (t < s.NT) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int ri = 4 * t + b;
+                            put(j, b, ri < s.RQ ? s.plan.tap[qq][ri] : -1, 8);
+                        }
+                    } else if (s.ODD && t - s.NT < 2) {
+                        const int krow = s.plan.tap[qq][s.RQ - 1];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) put(j, b, krow, 4 * (t - s.NT) + b);
+                    }
+                }
+            }
+        }
+        Wd[(st * 3 + 0) * 64 + l] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+        Wd[(st * 3 + 1) * 64 + l] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        Wd[(st * 3 + 2) * 64 + l] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+    }
+    for (int i = tid; i < s.NP * 4; i += kThreads) {
+        const int qq = i & 3, st = i >> 2;
+        roff[i] = make_int2(s.plan.halo[qq][2 * st] * (DW * 4), s.plan.halo[qq][2 * st + 1] * (DW * 4));
+    }
+    for (int i = tid; i < s.NT * 4; i += kThreads) {
+        const int qq = i & 3, t = i >> 2;
+        int o[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ri = 4 * t + b;
+            o[b] = s.plan.halo[qq][ri < s.RQ ? ri : s.RQ - 1] * (DW * 4);
+        }
+        toff[i] = make_int4(o[0], o[1], o[2], o[3]);
+    }
+    if (tid < 4) oddoff[tid] = s.plan.halo[tid][s.RQ - 1] * (DW * 4);
+    SN_ST(3);
+
+    // lambda_g * scale_g next to the scales: the epilogue reads its four of each per round (16-byte LDS reads) instead
+    // of holding eight registers through the MFMA loop
+    if (tid < 16) lamsc[tid] = (out && tid < s.G) ? lambdas[tid] * scale[tid] : 0.0f;
+    if (my_tiles == 0 || (s.dbg & 8)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the first two halos are in
+    __syncthreads();                                   // tables complete, every wave's pieces in: no counters needed yet
+    SN_ST(4);
+    if (wave >= kWaves / 2 && s.stagger > 0)           // once: the younger wave of every SIMD pair runs half a round behind
+        for (int i = 0; i < s.stagger; i += 100) __builtin_amdgcn_s_sleep(100);
+
+    const int half_tx = s.TX >> 1;
+    const int nrounds = s.TZ * half_tx;
+    const size_t V = (size_t)s.Z * s.X * s.Y;
+    bool healthy = true;
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * gridDim.x;
+        const TileCoord c = tile_coord(s, tile);
+        const int bi = it % kNB;
+        const uint8_t* hb = reinterpret_cast<const uint8_t*>(hbuf + (size_t)bi * hdw);
+        // halo `it` is complete once every wave has seen its own DMA pieces land (tiles 0 and 1: the barrier above)
+        const unsigned long long t_tile = SN_WNOW();
+        if (it >= 2) healthy &= wave_wait(&landed[bi], kWaves * (it / kNB + 1 - (bi < 2 ? 1 : 0)));
+        SN_WT(0, t_tile);
+        const bool dma_next = it + 2 < my_tiles && !(s.dbg & 2);
+        // this wave's pieces of halo it+2.  Its ring slot was last read by tile it-1: every wave must be past that
+        // tile -- two rounds into tile `it` they are ([measured] one round in, waves 0-3 waited ~4 us per tile for the
+        // younger wave of their SIMD); a wave with fewer rounds issues after them
+        bool dma_pending = dma_next;
+        auto dma_ahead = [&]() {
+            const int bn = (it + 2) % kNB;
+            if (it >= 1) healthy &= wave_wait(&done[bn], kWaves * ((it - 1) / kNB + 1));
+            // (the lane constants are recomputed here, ~15 instructions per tile, rather than kept in registers through the rounds)
+            halo_dma_issue(hbuf + (size_t)bn * hdw, x, s, tile_coord(s, tile + 2 * gridDim.x), dma_lane(s, wave, lane), wave);
+            dma_pending = false;
+        };
+        const int k_dma = (nrounds - wave + kWaves - 1) / kWaves >= 3 ? 2 : 1;
+        int k = 0;
+        for (int round = wave; round < nrounds; round += kWaves, ++k) {
+            const unsigned long long t_r0 = SN_WNOW();
+            if (k == k_dma && dma_pending) dma_ahead();
+            SN_WT(4, t_r0);
+            const unsigned long long t_r1 = SN_WNOW();
+            if ((s.dbg & 128) && wave >= kWaves / 2) continue;   // timing experiment: one wave per SIMD works
+            const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
+            const uint8_t* xb = hb + ((lz * s.XP + lx) * DW + n + D0) * 4;
+
+            i32x4 acc[3][NV];   // not zeroed: the first step's MFMAs take the constant 0 as their C operand
+
+            auto load_w = [&](int st, i32x4 (&w)[3]) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint4 u = Wd[(st * 3 + d) * 64 + lane];
+                    w[d] = i32x4{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
+                }
+            };
+            // raw dwords D0 D1 D2 of kernel rows A, B for x-rows h = 0, 1: [h][e][c]
+            auto load_raw = [&](const int2& ro, uint32_t (&d)[2][2][3]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t* p = reinterpret_cast<const uint32_t*>(xb + (e ? ro.y : ro.x) + h * (DW * 4));
+                        d[h][e][0] = p[0];
+                        d[h][e][1] = p[1];
+                        d[h][e][2] = p[2];
+                    }
+            };
+            auto mma_tile = [&](const i32x4 (&w)[3], const i32x4& xv, int v, bool first = false) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv, first ? i32x4{0, 0, 0, 0} : acc[d][v], 0, 0, 0);
+            };
+            auto pair_compute = [&](const i32x4 (&w)[3], const uint32_t (&d)[2][2][3], bool first = false) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t a0 = d[h][0][0], a1 = d[h][0][1], a2 = d[h][0][2];
+                    const uint32_t b0 = d[h][1][0], b1 = d[h][1][1], b2 = d[h][1][2];
+                    mma_tile(w, i32x4{(int)a0, (int)a1, (int)b0, (int)b1}, 4 * h + 0, first);
+                    mma_tile(w, i32x4{(int)window<1>(a1, a0), (int)window<1>(a2, a1), (int)window<1>(b1, b0),
+                                      (int)window<1>(b2, b1)}, 4 * h + 1, first);
+                    mma_tile(w, i32x4{(int)window<2>(a1, a0), (int)window<2>(a2, a1), (int)window<2>(b1, b0),
+                                      (int)window<2>(b2, b1)}, 4 * h + 2, first);
+                    mma_tile(w, i32x4{(int)window<3>(a1, a0), (int)window<3>(a2, a1), (int)window<3>(b1, b0),
+                                      (int)window<3>(b2, b1)}, 4 * h + 3, first);
+                }
+            };
+
+            constexpr std::integral_constant<int, 0> I0{};
+            constexpr std::integral_constant<int, 1> I1{};
+            // raw dwords of a tail step for x-row h, [j][b]: a quad slot holds D2 of its four kernel rows; an odd-row chunk
+            // slot holds D_c, D_c+1 in b = 0, 1
+            auto tail_load = [&](auto TS, auto H, uint32_t (&raw)[4][4]) {
+                constexpr int ts = decltype(TS)::value, h = decltype(H)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * ts + j;
+                    if (t < NT) {
+                        const int4 to = toff[t * 4 + q];
+                        const uint8_t* p = xb + h * (DW * 4) + 8;
+                        raw[j][0] = *reinterpret_cast<const uint32_t*>(p + to.x);
+                        raw[j][1] = *reinterpret_cast<const uint32_t*>(p + to.y);
+                        raw[j][2] = *reinterpret_cast<const uint32_t*>(p + to.z);
+                        raw[j][3] = *reinterpret_cast<const uint32_t*>(p + to.w);
+                    } else if (ODD && t - NT < 2) {
+                        const uint32_t* p = reinterpret_cast<const uint32_t*>(xb + h * (DW * 4) + oddoff[q] + 4 * (t - NT));
+                        raw[j][0] = p[0];
+                        raw[j][1] = p[1];
+                        raw[j][2] = 0u;
+                        raw[j][3] = 0u;
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) raw[j][b] = 0u;
+                    }
+                }
+            };
+            auto tail_compute = [&](auto TS, auto H, const uint32_t (&raw)[4][4], const i32x4 (&w)[3]) {
+                constexpr int ts = decltype(TS)::value, h = decltype(H)::value;
+                uint32_t xr[4][4];   // [residue][j]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * ts + j;
+                    if (t < NT) {
+                        uint32_t o[4];
+                        transpose4(raw[j][0], raw[j][1], raw[j][2], raw[j][3], o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xr[r][j] = o[r];
+                    } else {   // odd-row chunk (or an unused slot: all zero)
+                        const uint32_t lo = raw[j][0], hi = raw[j][1];
+                        xr[0][j] = lo;
+                        xr[1][j] = window<1>(hi, lo);
+                        xr[2][j] = window<2>(hi, lo);
+                        xr[3][j] = window<3>(hi, lo);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mma_tile(w, i32x4{(int)xr[r][0], (int)xr[r][1], (int)xr[r][2], (int)xr[r][3]}, 4 * h + r);
+            };
+
+            // ---- pair steps, two register sets: step st+1's operands are requested before step st's 24 MFMAs issue; the
+            // first tail step's raw dwords are requested ahead of the last pair step's MFMAs in the same way
+            i32x4 wa[3], wb[3];
+            uint32_t da[2][2][3], db[2][2][3];
+            uint32_t ta[4][4], tb[4][4];   // tail raw dwords, one (step, x-row) each, ping-pong
+            int2 ra = roff[q], rb;
+            load_w(0, wa);
+            load_raw(ra, da);
+            rb = roff[(NP > 1 ? 4 : 0) + q];
+            __builtin_amdgcn_sched_barrier(0);
+            // steps in pairs while at least one more follows; the last one or two are peeled below so that the tail's
+            // raw dwords are live only there (carried through the loop they cost 32 registers: the kernel spilled)
+            const int np_loop = (NP - 1) & ~1;   // >= 2 (NP = 10)
+            {   // steps 0 and 1; step 0 opens the accumulators
+                load_w(1, wb);
+                load_raw(rb, db);
+                ra = roff[2 * 4 + q];
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wa, da, true);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(2, wa);
+                load_raw(ra, da);
+                rb = roff[(3 < NP ? 3 : NP - 1) * 4 + q];
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wb, db);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            int st = 2;
+            for (; st < np_loop; st += 2) {
+                load_w(st + 1, wb);
+                load_raw(rb, db);
+                ra = roff[(st + 2) * 4 + q];
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wa, da);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(st + 2, wa);
+                load_raw(ra, da);
+                rb = roff[(st + 3 < NP ? st + 3 : NP - 1) * 4 + q];
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wb, db);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (NP - np_loop == 2) {
+                load_w(np_loop + 1, wb);
+                load_raw(rb, db);
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wa, da);
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(NP, wa);   // the first tail step's digits
+                tail_load(I0, I0, ta);
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wb, db);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                load_w(NP, wb);
+                tail_load(I0, I0, ta);
+                __builtin_amdgcn_sched_barrier(0);
+                pair_compute(wa, da);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) wa[d] = wb[d];
+            }
+            SN_WT(1, t_r1);
+            const unsigned long long t_r2 = SN_WNOW();
+            // ---- tail steps (at most two; the first one's digits are in wa, its x-row 0 raw dwords in ta): the raw dwords
+            // of the next (step, x-row) are requested before the 12 MFMAs of the current one
+            if (NTS > 1) load_w(NP + 1, wb);
+            tail_load(I0, I1, tb);
+            __builtin_amdgcn_sched_barrier(0);
+            tail_compute(I0, I0, ta, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTS > 1) tail_load(I1, I0, ta);
+            __builtin_amdgcn_sched_barrier(0);
+            tail_compute(I0, I1, tb, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (NTS > 1) {
+                tail_load(I1, I1, tb);
+                __builtin_amdgcn_sched_barrier(0);
+                tail_compute(I1, I0, ta, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                tail_compute(I1, I1, tb, wb);
+            }
+            SN_WT(2, t_r2);
+            const unsigned long long t_r3 = SN_WNOW();
+            // ---- epilogue: recombine the digits, bank activations, head
+            const int gz = c.z0 + lz;
+            if (gz >= s.Z) continue;
+            if (s.dbg & 1) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(acc[d][v]));
+                continue;
+            }
+            float val[NV][4];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int low = acc[1][v][r] * 256 + acc[0][v][r];   // |.| < 2^25: exact
+                    val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);
+                }
+            const int gy4 = c.y0 + 4 * n;   // this lane's four residues: y = gy4 .. gy4 + 3
+            const float4 sc4 = *reinterpret_cast<const float4*>(scale + 4 * q);
+            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+            if (act && gy4 < s.Y) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int gx = c.x0 + lx + h;
+                    if (gx < s.X) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g = 4 * q + r;
+                            if (g < s.G) {
+                                OT* o = act + ((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy4;
+                                const float v0 = val[4 * h + 0][r] * sc[r], v1 = val[4 * h + 1][r] * sc[r],
+                                            v2 = val[4 * h + 2][r] * sc[r], v3 = val[4 * h + 3][r] * sc[r];
+                                if constexpr (sizeof(OT) == 4) {
+                                    *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
+                                } else {
+                                    reinterpret_cast<double2*>(o)[0] = make_double2((double)v0, (double)v1);
+                                    reinterpret_cast<double2*>(o)[1] = make_double2((double)v2, (double)v3);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (out) {
+                const float4 lam4 = *reinterpret_cast<const float4*>(lamsc + 4 * q);
+                const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
+                float pm[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float p = lam[0] * val[v][0];
+                    p = fmaf(lam[1], val[v][1], p);
+                    p = fmaf(lam[2], val[v][2], p);
+                    pm[v] = fmaf(lam[3], val[v][3], p);
+                }
+                // sum over the four lane groups (the 16 kernels) with half / row swaps: one v_permlane32_swap + add sums
+                // TWO tiles over lanes (l, l + 32) -- tile a ends in the lower half, b in the upper --, one
+                // v_permlane16_swap + add does the same inside the halves.  Lane group q ends up holding exactly what it
+                // stores: x-row q >> 1, residues 2 (q & 1) and 2 (q & 1) + 1 (12 VALU; eight ds_bpermute pairs before).
+                auto sum_halves = [&](float a, float b) -> float {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                };
+                auto sum_rows = [&](float u, float w) -> float {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                };
+                const float e0 = sum_rows(sum_halves(pm[0], pm[4]), sum_halves(pm[2], pm[6]));   // rows: tiles 0 2 4 6
+                const float e1 = sum_rows(sum_halves(pm[1], pm[5]), sum_halves(pm[3], pm[7]));   // rows: tiles 1 3 5 7
+                const int h = q >> 1;
+                const int gx = c.x0 + lx + h, gy = gy4 + 2 * (q & 1);
+                if (gx < s.X && gy < s.Y) {
+                    OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
+                    float t0 = e0, t1 = e1;
+                    if (s.head & 1) { t0 += (float)load_now(o); t1 += (float)load_now(o + 1); }
+                    if (s.head & 2) { t0 = relu_tanh(t0); t1 = relu_tanh(t1); }
+                    if constexpr (sizeof(OT) == 4) *reinterpret_cast<float2*>(o) = make_float2(t0, t1);
+                    else *reinterpret_cast<double2*>(o) = make_double2((double)t0, (double)t1);
+                }
+            }
+            SN_WT(3, t_r3);
+        }
+        // ---- this wave is through with tile `it`
+        const unsigned long long t_e = SN_WNOW();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_signal(&done[bi], lane);
+        if (dma_pending) dma_ahead();
+        if (dma_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and its stores) have landed
+            wave_signal(&landed[(it + 2) % kNB], lane);
+        }
+        SN_WT(5, t_e);
+        SN_WT(6, t_tile);
+    }
+    if (!healthy && lane == 0) flags[1] = 1;
+    SN_ST(5);
+}
+
+size_t lds_bytes(const Shape& s) {
+    const size_t hdw = (size_t)s.ZP * s.XP * DW;
+    return (size_t)s.KS * 3 * 64 * 16 + (size_t)s.NP * 4 * 8 + (size_t)s.NT * 4 * 16 + 16 + 64 + 64 + 128 + 128 + 48 +
+           (kNB * hdw * 4 > 2 * hdw * 4 + ((size_t)s.G * s.kz * s.kx * 9 + 1) * sizeof(float)
+                ? kNB * hdw * 4 : 2 * hdw * 4 + ((size_t)s.G * s.kz * s.kx * 9 + 1) * sizeof(float)) + 16;
+}
+
+int num_cus() {
+    static thread_local int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    cached = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    return cached;
+}
+
+// Kernel rows -> lane groups.  The two lane groups an LDS cycle serves (q = 0,1 and q = 2,3) read the rows at the
+// same list position: with 24-dword halo rows they fall on disjoint banks when the halo row indices differ by 2
+// (mod 4).  Rows are bucketed by halo index mod 4 and class c is paired with class c + 2; what is left over pairs up
+// among itself (a 2-way conflict on those reads) or with a pad.  Any assignment is correct; this one is fast.
+bool plan_rows(int kz, int kx, int XP, RowPlan& p, int& RQ) {
+    const int R = kz * kx;
+    RQ = (R + 3) / 4;
+    if (RQ > kMaxRQ || RQ < 1) return false;
+    static_assert((2 * DW) % 32 == 16, "plan_rows pairs halo rows 2 (mod 4) apart: 2 * DW must be 16 (mod 32) dwords");
+    std::vector<int> cls[4];
+    for (int dz = 0; dz < kz; ++dz)
+        for (int dx = 0; dx < kx; ++dx) cls[(dz * XP + dx) & 3].push_back(dz * kx + dx);
+    std::vector<std::pair<int, int>> units;
+    std::vector<int> singles;
+    for (int c = 0; c < 2; ++c) {
+        const auto &a = cls[c], &b = cls[c + 2];
+        const size_t m = a.size() < b.size() ? a.size() : b.size();
+        for (size_t i = 0; i < m; ++i) units.emplace_back(a[i], b[i]);
+        for (size_t i = m; i < a.size(); ++i) singles.push_back(a[i]);
+        for (size_t i = m; i < b.size(); ++i) singles.push_back(b[i]);
+    }
+    for (size_t i = 0; i + 1 < singles.size(); i += 2) units.emplace_back(singles[i], singles[i + 1]);
+    if (singles.size() & 1) units.emplace_back(singles.back(), -1);
+    if ((int)units.size() > 2 * RQ) return false;   // cannot happen: ceil(R / 2) <= 2 ceil(R / 4)
+    auto halo_of = [&](int krow) { return (krow / kx) * XP + (krow % kx); };
+    for (int qq = 0; qq < 4; ++qq)
+        for (int i = 0; i < kMaxRQ; ++i) { p.halo[qq][i] = 0; p.tap[qq][i] = -1; }
+    for (size_t u = 0; u < units.size(); ++u) {
+        const int half = (int)(u & 1), pos = (int)(u >> 1);
+        const int a = units[u].first, b = units[u].second;
+        p.tap[2 * half][pos] = (short)a;
+        p.halo[2 * half][pos] = (short)halo_of(a);
+        p.tap[2 * half + 1][pos] = (short)b;
+        p.halo[2 * half + 1][pos] = (short)(b >= 0 ? halo_of(b) : halo_of(a));   // pad: same address, a broadcast
+    }
+    return true;
+}
+
+}  // namespace
+
+namespace sn {
+
+int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
+                    int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                    sn_stream_t stream);   // conv.hip
+
+// returns SN_OK, an error, or 1 when this shape is not served here (caller tries conv_occ_i8, then fp32)
+int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int Gtot,
+                 int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype, hipStream_t stream) {
+    if (ky != 9 || kz * kx != 81 || Y % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || G > 16) return 1;
+    if (act && (reinterpret_cast<uintptr_t>(act) & 15)) return 1;
+    if (out && (reinterpret_cast<uintptr_t>(out) & 15)) return 1;
+    if (sn::option_conv_skip_empty_tiles()) return 1;   // data-dependent tile skipping lives in conv_i8.hip
+    Shape s;
+    memset(&s, 0, sizeof(s));
+    s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx;
+    s.Gtot = Gtot; s.g0 = g0; s.head = head;
+    s.gate = sn::current_gate();
+    s.nyt = (Y + TY - 1) / TY;
+    const char* dbg = getenv("SN_CONV_I8_DBG");
+    s.dbg = dbg ? atoi(dbg) : 0;
+    const char* stg = getenv("SN_CONV_I8S_STAGGER");
+    s.stagger = stg ? atoi(stg) : 100;   // x 64 clocks: about half a round
+    const int cus = num_cus();
+    static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
+    bool found = false;
+    for (const auto& c : cand) {
+        s.TZ = c[0]; s.TX = c[1];
+        s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
+        const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
+        if (nt > 0x7fffffff) return 1;
+        s.ntiles = (int)nt;
+        s.ZP = s.TZ + kz - 1;
+        s.XP = (s.TX + kx - 1) | 1;   // odd: rows of different z planes can pair up 2 (mod 4) apart
+        if (!plan_rows(kz, kx, s.XP, s.plan, s.RQ)) return 1;
+        s.ODD = s.RQ & 1;
+        s.NP = s.RQ / 2;
+        s.NT = (s.RQ + 3) / 4;
+        s.NTS = (s.NT + 2 * s.ODD + 3) / 4;
+        s.KS = s.NP + s.NTS;
+        // one instantiation: 81 kernel rows (9 x 9) = 10 pair steps, 6 quads, an odd row.  (The run-time form of the step
+        // structure compiles, and is correct, but spills: hipcc keeps two copies of the accumulators across its joins.)
+        if (s.NP != 10 || s.NT != 6 || s.ODD != 1) return 1;
+        if (s.ZP * s.XP > 32767) continue;
+        if (lds_bytes(s) > (size_t)kMaxLds) continue;
+        found = true;
+        if (s.ntiles >= 4 * cus) break;
+    }
+    if (!found) return 1;
+    // quantisation guard (see the header): tolerance on the worst-case activation error of the int8 path
+    s.tol = sn::option_conv_i8_tolerance();
+    s.route = nullptr;
+    if (s.tol > 0.0f) {
+        s.route = sn::device_flag_slot();
+        if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
+    }
+    const int grid = cus < s.ntiles ? cus : s.ntiles;
+    const size_t lds = lds_bytes(s);
+#define SN_LAUNCH_I8S(OT)                                                                                        \
+    do {                                                                                                         \
+        auto kern = conv_occ_i8s_kernel<OT, 10, 6, 1>;                                                           \
+        if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
+            return check_launch("sn_conv_bank(i8s: hipFuncSetAttribute)");                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (OT*)act,         \
+                           (OT*)out);                                                                            \
+    } while (0)
+    if (out_dtype == SN_F32) SN_LAUNCH_I8S(float);
+    else SN_LAUNCH_I8S(double);
+#undef SN_LAUNCH_I8S
+    if (int rc = check_launch("sn_conv_bank(i8s)")) return rc;
+    if (s.route) {
+        // the same launch on the fp32 matrix pipe, enqueued behind: runs only if the guard above sent it here
+        sn::GateScope guard(s.route, 1);
+        return sn::conv_bank_group(x, SN_U8, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky, act, out,
+                                   out_dtype, reinterpret_cast<sn_stream_t>(stream));
+    }
+    return SN_OK;
+}
+
+}  // namespace sn
+
+#ifdef SN_CONV_TIMING
+extern "C" void sn_debug_i8s_times(unsigned long long* host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_i8s_t), sizeof(unsigned long long) * 1024 * 16);
+    (void)hipMemcpyFromSymbol(host + 1024 * 16, HIP_SYMBOL(g_i8s_w), sizeof(unsigned long long) * 1024 * 64);
+}
+#endif

@@ -57,8 +57,9 @@ struct LinShape {
     int npairs, nsteps;   // kernel rows (dz,dx); MFMA steps = ceil(npairs / 2)
     int XP, rows, NRP;    // halo rows per z plane, total halo rows, rows padded to a multiple of 16
     int PYA;              // halo origin in y = y0 - PYA, PYA = roundup(py, 4) (aligned global dwords)
-    const int32_t* gate;  // run only if null or *gate == gate_want (common.h: Gate)
-    int gate_want;
+    sn::Gate gate;       // run only if every condition holds (common.h: Gate)
+    int32_t* route;       // out: 1 = K*'s quantisation bound exceeded (the gated fp32 launches behind take over), else 0
+    float tol;            // bound on the worst-case pre-activation error allowed here (<= 0: no check)
     int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 16 no deferral
 };
 
@@ -77,11 +78,11 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #ifdef SN_CONV_TIMING
     if (threadIdx.x == 0) g_lin_t[blockIdx.x * 16 + 0] = wall_clock64();
 #endif
-    if (s.gate && *s.gate != s.gate_want) return;
+    if (!s.gate.pass()) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint4* At = reinterpret_cast<uint4*>(lds);                                  // [nsteps + 1][3][64], last step zero
-    float* misc = reinterpret_cast<float*>(At + (size_t)(s.nsteps + 1) * 3 * 64);                // [16]: scale, per-wave maxima
-    int* offtab = reinterpret_cast<int*>(misc + 16);                            // kW24: [(nsteps + 3) * 8] piece -> halo offset
+    float* misc = reinterpret_cast<float*>(At + (size_t)(s.nsteps + 1) * 3 * 64);                // [64]: scale, per-wave maxima, error sums
+    int* offtab = reinterpret_cast<int*>(misc + 64);                            // kW24: [(nsteps + 3) * 8] piece -> halo offset
     uint8_t* halo = reinterpret_cast<uint8_t*>(offtab + (kW24 ? (s.nsteps + 3) * 8 : 0));   // [NC][NRP] x 16 bytes
     float* kstar = reinterpret_cast<float*>(halo);                              // [ntaps] (prologue only; aliases halo)
 
@@ -198,16 +199,15 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     if (lane == 0) wmax[wave] = mx;
     __syncthreads();
     SN_LT(5);
-    int F = 0;
+    // 24-bit fixed point over the whole range of three balanced digits: Q = rint(K* . S) in fp64, S = 8355711 / max|K*|
+    double S = 0.0, invS = 0.0;
     {
         float m = 0.0f;
         for (int w = 0; w < kWaves; ++w) m = (m != m || wmax[w] != wmax[w]) ? __int_as_float(0x7fc00000) : fmaxf(m, wmax[w]);
-        int e = 0;
-        if (m > 0.0f) (void)frexpf(m, &e);   // m <= 2^e
-        F = 22 - e;
-        if (tid == 0) misc[0] = (m != m) ? m : ldexpf(1.0f, -F);
+        if (m > 0.0f) { S = 8355711.0 / (double)m; invS = (double)m / 8355711.0; }   // NaN: comparison false, S = 0 and the scale below is NaN
+        if (tid == 0) misc[0] = (m != m) ? m : (float)((double)m / 8355711.0);
     }
-    const float twoF = ldexpf(1.0f, F);
+    double ep = 0.0, en = 0.0;   // this thread's share of the positive / negative quantisation errors
     // Each (kernel row p, digit d) as a zero-padded byte row R[64] with tap dy at byte 32 + dy; a table entry is the
     // 16-byte window of that row starting at byte 32 + 16 h - m - delta: five aligned dwords and four v_alignbyte
     // instead of quantising sixteen taps per entry (the table build was ~4 us of the prologue).
@@ -223,7 +223,13 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         for (int j = 0; j < 4; ++j) {
             const int dy = 4 * gq + j;
             if (dy < s.ky) {
-                int Q = __float2int_rn(kstar[p * s.ky + dy] * twoF);
+                const double wv = (double)kstar[p * s.ky + dy];
+                int Q = __double2int_rn(wv * S);
+                if (S > 0.0) {
+                    const double e = (double)Q * invS - wv;
+                    ep += e > 0.0 ? e : 0.0;
+                    en += e < 0.0 ? -e : 0.0;
+                }
                 const int d0 = ((Q + 128) & 255) - 128;
                 Q = (Q - d0) >> 8;
                 const int d1 = ((Q + 128) & 255) - 128;
@@ -237,7 +243,27 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         rpad[(p * 3 + 1) * RW + 8 + gq] = w1;
         rpad[(p * 3 + 2) * RW + 8 + gq] = w2;
     }
+    // the exact worst case of the quantisation error over all binary inputs: max(sum of the positive errors, sum of the
+    // negative ones).  Above the tolerance the launch is not run here: *route = 1 hands it to the fp32 contraction.
+    double* esum = reinterpret_cast<double*>(misc + 16);   // [kWaves][2]
+    if (s.tol > 0.0f) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ep += __shfl_xor(ep, o, 64);
+            en += __shfl_xor(en, o, 64);
+        }
+        if (lane == 0) { esum[2 * wave] = ep; esum[2 * wave + 1] = en; }
+    }
     __syncthreads();
+    if (s.tol > 0.0f) {
+        double tp = 0.0, tn = 0.0;
+        for (int w = 0; w < kWaves; ++w) { tp += esum[2 * w]; tn += esum[2 * w + 1]; }
+        const bool exceeded = (tp > tn ? tp : tn) > (double)s.tol;
+        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
+        if (exceeded) return;   // the halo loads requested above have register destinations: nothing is left in flight
+    } else if (blockIdx.x == 0 && tid == 0 && s.route) {
+        *s.route = 0;
+    }
     SN_LT(6);
     for (int i = tid; i < (s.nsteps + 1) * 64; i += kThreads) {
         const int st = i >> 6, l = i & 63;
@@ -522,7 +548,7 @@ bool lin_plan(int B, int Z, int X, int Y, int G, int kz, int kx, int ky, LinShap
     const size_t halo = (size_t)s.NRP * YB;
     // prologue scratch aliasing the halo: K* and the padded digit rows
     const size_t kst = (((size_t)kz * kx * ky + 3) & ~(size_t)3) * sizeof(float) + (size_t)kz * kx * 3 * 17 * 4;
-    lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 64 + (w24 ? (size_t)(s.nsteps + 3) * 8 * 4 : 0) +
+    lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 256 + (w24 ? (size_t)(s.nsteps + 3) * 8 * 4 : 0) +
           (halo > kst ? halo : kst) + 16;
     return lds <= (size_t)kMaxLds;
 }
@@ -543,10 +569,16 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     size_t lds = 0;
     bool w24 = false;
     if (!lin_plan(B, Z, X, Y, G, kz, kx, ky, s, lds, w24)) return SN_ERR_UNSUPPORTED;
-    s.gate = sn::current_gate().ptr; s.gate_want = sn::current_gate().want;
+    s.gate = sn::current_gate();
     int grid = num_cus();
     if (grid > s.ntiles) grid = s.ntiles;
     s.dbg = getenv("SN_CONV_LIN_DBG") ? atoi(getenv("SN_CONV_LIN_DBG")) : 0;
+    s.tol = sn::option_conv_i8_tolerance();
+    s.route = nullptr;
+    if (s.tol > 0.0f) {
+        s.route = sn::device_flag_slot();
+        if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
+    }
 #define SN_LAUNCH_LIN(OT)                                                                                         \
     do {                                                                                                          \
         auto kern = w24 ? conv_lin_i8_kernel<OT, true> : conv_lin_i8_kernel<OT, false>;                           \
@@ -558,7 +590,19 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     else if (out_dtype == SN_F64) SN_LAUNCH_LIN(double);
     else return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: out_dtype %d", out_dtype);
 #undef SN_LAUNCH_LIN
-    return sn::check_launch("sn_conv_fused");
+    if (int rc = sn::check_launch("sn_conv_fused")) return rc;
+    if (s.route) {   // the 16-kernel contraction on the fp32 matrix pipe, enqueued behind: runs only if the guard sent it there
+        sn::GateScope guard(s.route, 1);
+        const size_t ntaps = (size_t)kz * kx * ky;
+        for (int g0 = 0; g0 < G; g0 += 16) {
+            const int gc = (G - g0 < 16) ? G - g0 : 16;
+            const int head = (g0 > 0 ? 1 : 0) | (g0 + gc >= G ? 2 : 0);
+            const int rc = sn::conv_bank_group(x, SN_U8, bank + g0 * ntaps, lambdas + g0, B, Z, X, Y, gc, G, g0, head, kz, kx,
+                                               ky, nullptr, out, out_dtype, reinterpret_cast<sn_stream_t>(stream));
+            if (rc != SN_OK) return rc;
+        }
+    }
+    return SN_OK;
 }
 
 // float grid -> bytes (x != 0) + "not binary" flag; 4 elements per thread iteration

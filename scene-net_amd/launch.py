@@ -46,6 +46,9 @@ def launch_ranks(n: int, script: str, argv: Sequence[str], extra_env: Optional[D
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, script, *argv], env=env))
+    if os.environ.get("SN_LAUNCH_VERBOSE") == "1":
+        print(f"launch_ranks: started {n} ranks of {os.path.basename(script)} (LOCAL_RANK 0..{n - 1}, port {port})",
+              file=sys.stderr, flush=True)
     rc = 0
     t0 = time.monotonic()
     live = list(procs)

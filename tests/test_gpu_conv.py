@@ -208,9 +208,10 @@ def test_occupancy_i8_against_oracle(hip_device, shape, ks, G):
     act, out = _hip.conv_bank(occ.to(hip_device), bank.to(hip_device).contiguous(), lam.to(hip_device),
                               want_act=True, want_out=True)
     assert act.dtype == torch.float32
-    # per kernel: error relative to that kernel's own scale (fixed point is per kernel)
+    # per kernel: the fixed point is per kernel, so the error scales with that kernel's own largest weight; the parity
+    # bar itself is relative to max(1, |act|) of that kernel
     for g in range(G):
-        scale = max(1.0, ref_act[:, g].abs().max().item()) * max(1.0, 0.0)
+        scale = max(1.0, ref_act[:, g].abs().max().item())
         wmax = bank[g].abs().max().item()
         err = (act[:, g].cpu().double() - ref_act[:, g]).abs().max().item()
         assert err < TOL * max(wmax, 1e-30) * 10 and err < TOL * scale, (g, err, wmax)
@@ -221,14 +222,20 @@ def test_occupancy_i8_against_oracle(hip_device, shape, ks, G):
     assert (act32 - act).abs().max().item() < TOL and (out32 - out).abs().max().item() < TOL
 
 
-def test_occupancy_i8_is_exact_for_exactly_representable_weights(hip_device):
-    """Integer accumulation: with weights that are multiples of 2^-10 the result is exact, whatever the order."""
+def test_occupancy_i8_integer_accumulation_is_exact(hip_device):
+    """Integer accumulation: a bank whose weights are integer multiples of max|W| / 8355711 is represented exactly by
+    the fixed point (the scale uses the whole range of three balanced digits), so the only error left is the fp32
+    recombination of the sum -- and the result does not depend on the order of accumulation."""
     torch.manual_seed(9)
     occ = torch.rand(4, 1, 32, 32, 64, device=hip_device) < 0.2
-    bank = (torch.randint(-1024, 1025, (16, 9, 9, 9)).float() / 1024).to(hip_device).contiguous()
+    q = torch.randint(-4194304, 4194305, (16, 9, 9, 9))   # |q| <= 2^22: the fp32 rounding of W moves W * S by < 0.5
+    q[:, 0, 0, 0] = 8355711                           # max|Q| = 8355711 -> S = 8355711 / max|W| reproduces q
+    bank64 = q.double() * (2.0 / 8355711.0)            # max|W| = 2
+    bank = bank64.float().to(hip_device).contiguous()   # fp32 rounding of the weights: rint(W * S) is still q
     act, _ = _hip.conv_bank(occ, bank, None, want_act=True, want_out=False)
-    ref = go.conv_bank(occ.cpu().double(), bank.cpu().double().unsqueeze(1))
-    assert torch.equal(act.cpu().double(), ref)
+    ref = go.conv_bank(occ.cpu().double(), bank64.unsqueeze(1))
+    rel = ((act.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert rel < 1e-6, rel                            # a few fp32 roundings of an exactly accumulated integer (unit 2.4e-7)
     act2, _ = _hip.conv_bank(occ, bank, None, want_act=True, want_out=False)
     assert torch.equal(act, act2)
 

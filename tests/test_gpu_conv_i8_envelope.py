@@ -1,0 +1,258 @@
+"""The int8 kernels' parity envelope on the MI355X: K3' in both forms (stride-4 kernel
+conv_i8s.hip, four-copy kernel conv_i8.hip) and K3L (conv_lin.hip) at occupancy densities the LiDAR-shaped tests never
+reach, with banks of large weights, at 128^3 -- each against the fp64 oracle, against the ANALYTIC bound of the
+24-bit fixed-point quantisation, and with the device-side route to the fp32 kernel checked where the bound cannot
+meet the tolerance.  Tolerance (north_star): activations within 1e-4 (relative to max(1, |act|))."""
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from scene_net_amd import _hip
+from oracle import geneo_oracle as go
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+QMAX = 8355711.0   # 127 * (1 + 256 + 65536): the magnitude three balanced base-256 digits hold
+
+
+def quant_bound(w):
+    """Worst case over all binary inputs of sum_t (Q_t / S - w_t) x_t for Q = rint(w S), S = QMAX / max|w| -- what the
+    kernels' prologue computes (conv_i8s.hip): max(sum of the positive errors, sum of the negative errors)."""
+    w = np.asarray(w, dtype=np.float64).reshape(-1)
+    m = np.abs(w).max()
+    if m == 0:
+        return 0.0
+    S = QMAX / m
+    e = np.rint(w * S) / S - w
+    return float(max(e[e > 0].sum(), -e[e < 0].sum()))
+
+
+class legacy_kernel:
+    """sn_set_option("conv_i8_legacy", 1): the four-copy int8 kernel for every shape."""
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        _hip.set_option("conv_i8_legacy", 1 if self.on else 0)
+
+    def __exit__(self, *a):
+        _hip.set_option("conv_i8_legacy", 0)
+
+
+def _bench_bank(dev, sigma_scale=1.0):
+    from scene_net_amd.synthetic import synthetic_bank_spec
+    specs, names, lambdas, last = synthetic_bank_spec()
+    if sigma_scale != 1.0:
+        specs = [(k, dict(p, sigma=p["sigma"] * sigma_scale)) for k, p in specs]
+    bank = go.geneo_bank(specs, (9, 9, 9))[:, 0].float()
+    lam = go.effective_lambdas(lambdas, last, names)
+    return bank, lam
+
+
+def _check_against_oracle(occ, bank, lam, dev, expect_route=None, what=""):
+    """conv_bank on bool occupancy vs the fp64 oracle; returns per-kernel errors.  expect_route: None = decide from the
+    analytic bound like the device does."""
+    G = bank.shape[0]
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    bounds = np.array([quant_bound(bank[g].numpy()) for g in range(G)])
+    mixed = float((lam.abs().double().numpy() * bounds).sum())
+    tol_dev = 1e-9 * _hip.get_option("conv_i8_tolerance_ppb")
+    routed = bool(bounds.max() > tol_dev or mixed > tol_dev)
+    if expect_route is not None:
+        assert routed == expect_route, (what, bounds.max(), mixed)
+    x = occ.to(dev)
+    b, l = bank.to(dev).contiguous(), lam.float().to(dev)
+    act, out = _hip.conv_bank(x, b, l, want_act=True, want_out=True)
+    a32, o32 = _hip.conv_bank(x.view(torch.uint8), b, l, want_act=True, want_out=True)   # the fp32 matrix pipe
+    if routed:   # the guard sent the launch to the fp32 kernel: same bits as calling it directly
+        assert torch.equal(act, a32) and torch.equal(out, o32), what
+    errs = []
+    for g in range(G):
+        amax = ref_act[:, g].abs().max().item()
+        err = (act[:, g].cpu().double() - ref_act[:, g]).abs().max().item()
+        errs.append(err)
+        assert err < TOL * max(1.0, amax), (what, g, err, amax)
+        if not routed:   # the fixed-point error is bounded by the table's own worst case (+ the fp32 recombination)
+            assert err <= bounds[g] + 4e-7 * max(1.0, amax), (what, g, err, bounds[g])
+            assert bounds[g] <= tol_dev
+    e_out = (out.cpu().double() - ref_out).abs().max().item()
+    assert e_out < TOL, (what, e_out)
+    return np.array(errs), bounds, routed
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+@pytest.mark.parametrize("density", [0.5, 1.0])
+def test_bench_bank_dense_occupancy(hip_device, density, legacy):
+    """BASELINE C2's GENEO bank (max|W| 0.1 .. 1.85) on half-full and completely full grids: int8 path, inside its bound."""
+    torch.manual_seed(int(density * 10))
+    occ = torch.rand(1, 1, 24, 24, 64) < density if density < 1 else torch.ones(1, 1, 24, 24, 64, dtype=torch.bool)
+    bank, lam = _bench_bank(hip_device)
+    with legacy_kernel(legacy):
+        errs, bounds, routed = _check_against_oracle(occ, bank, lam, hip_device, expect_route=False,
+                                                     what=f"bench bank d={density} legacy={legacy}")
+    print(f"density {density} legacy {legacy}: max err {errs.max():.2e}, max bound {bounds.max():.2e}, "
+          f"max|W| {bank.abs().max().item():.2f}")
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+@pytest.mark.parametrize("density", [0.5, 1.0])
+def test_large_sigma_bank_routes_to_fp32(hip_device, density, legacy):
+    """sigma x 4 (max|W| > 4): the worst-case fixed-point error exceeds 9e-5, so the device hands the launch to the fp32
+    kernel -- output bit-identical to the fp32 kernel's, inside 1e-4 * max(1, |act|) of the oracle."""
+    torch.manual_seed(3)
+    occ = torch.rand(1, 1, 16, 16, 64) < density if density < 1 else torch.ones(1, 1, 16, 16, 64, dtype=torch.bool)
+    bank, lam = _bench_bank(hip_device, sigma_scale=4.0)
+    assert bank.abs().max().item() >= 4.0
+    with legacy_kernel(legacy):
+        _check_against_oracle(occ, bank, lam, hip_device, expect_route=True, what=f"sigma x4 d={density}")
+    # with the guard off the int8 kernels run anyway, and stay inside the analytic bound (which is above the bar)
+    old = _hip.get_option("conv_i8_tolerance_ppb")
+    _hip.set_option("conv_i8_tolerance_ppb", 0)
+    try:
+        with legacy_kernel(legacy):
+            x = occ.to(hip_device)
+            act, _ = _hip.conv_bank(x, bank.to(hip_device).contiguous(), None, want_act=True, want_out=False)
+    finally:
+        _hip.set_option("conv_i8_tolerance_ppb", old)
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    for g in range(bank.shape[0]):
+        err = (act[:, g].cpu().double() - ref_act[:, g]).abs().max().item()
+        assert err <= quant_bound(bank[g].numpy()) + 4e-7 * max(1.0, ref_act[:, g].abs().max().item())
+
+
+@pytest.mark.parametrize("density", [0.3, 1.0])
+def test_trained_checkpoint_scalars_dense(hip_device, density):
+    """The 13 trained scalars of the reference's committed checkpoint (kernel (9,5,5): the four-copy kernel)."""
+    specs = [("cy", dict(radius=0.998896, sigma=1.199054)),
+             ("cone", dict(apex=0.0, cone_inc=0.565547, cone_radius=4.000988, radius=1.5, sigma=0.955910)),
+             ("neg", dict(neg_factor=0.127053, radius=3.000918, sigma=0.605097))]
+    names = ["cy_0", "cone_0", "neg_0"]
+    lam = torch.tensor([0.024178, 0.608911, 0.366911])
+    bank = go.geneo_bank(specs, (9, 5, 5))[:, 0].float()
+    torch.manual_seed(1)
+    occ = torch.rand(2, 1, 20, 20, 64) < density if density < 1 else torch.ones(2, 1, 20, 20, 64, dtype=torch.bool)
+    _check_against_oracle(occ, bank, lam, hip_device, expect_route=False, what=f"ckpt d={density}")
+    # and through linearity (K3L)
+    x = occ.to(hip_device)
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, 3, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    out = _hip.conv_fused(x, bank.to(hip_device).contiguous(), lam.to(hip_device))
+    assert (out.cpu().double() - ref_out).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("density,sigma_scale", [(0.5, 1.0), (1.0, 1.0), (1.0, 6.0)])
+def test_fused_linear_dense_and_large_sigma(hip_device, density, sigma_scale):
+    """K3L: one combined kernel K* = sum lambda K.  Its worst-case quantisation error is checked on the device; a K* that
+    cannot meet the tolerance (sigma x 6) is computed by the fp32 contraction instead."""
+    torch.manual_seed(5)
+    occ = torch.rand(1, 1, 16, 16, 64) < density if density < 1 else torch.ones(1, 1, 16, 16, 64, dtype=torch.bool)
+    bank, lam = _bench_bank(hip_device, sigma_scale=sigma_scale)
+    G = bank.shape[0]
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    kstar = np.zeros(729, dtype=np.float32)   # the kernel's own fp32 fma chain over the kernels, in order
+    for g in range(G):
+        kstar = (np.float32(lam[g].item()) * bank[g].numpy().reshape(-1).astype(np.float32) + kstar).astype(np.float32)
+    bound = quant_bound(kstar)
+    tol_dev = 1e-9 * _hip.get_option("conv_i8_tolerance_ppb")
+    x = occ.to(hip_device)
+    b, l = bank.to(hip_device).contiguous(), lam.float().to(hip_device)
+    out = _hip.conv_fused(x, b, l)
+    err = (out.cpu().double() - ref_out).abs().max().item()
+    print(f"K3L d={density} sigma x{sigma_scale}: err {err:.2e} bound {bound:.2e} max|K*| {np.abs(kstar).max():.3f}")
+    assert err < TOL
+    if bound > tol_dev * 1.01:
+        _, o32 = _hip.conv_bank(x.view(torch.uint8), b, l, want_act=False, want_out=True)
+        assert torch.equal(out, o32)        # routed: the fp32 contraction's bits
+    elif bound < tol_dev * 0.99:
+        assert err <= bound + 1e-6          # tanh is 1-Lipschitz: the pre-activation bound carries over
+    assert (sigma_scale > 1.0) == (bound > tol_dev)   # the case list covers both sides of the guard
+
+
+def test_128_cubed_tile_int8_kernels_against_oracle(hip_device):
+    """BASELINE C3's grid: one 128^3 tile through K3' (both forms) and K3L against the fp64 oracle."""
+    rng = np.random.default_rng(11)
+    occ = torch.from_numpy(rng.random((1, 1, 128, 128, 128)) < 0.035)
+    bank, lam = _bench_bank(hip_device)
+    G = bank.shape[0]
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    x = occ.to(hip_device)
+    b, l = bank.to(hip_device).contiguous(), lam.float().to(hip_device)
+    outs = {}
+    for legacy in (False, True):
+        with legacy_kernel(legacy):
+            act, out = _hip.conv_bank(x, b, l, want_act=True, want_out=True)
+        e_act = (act.cpu().double() - ref_act).abs().max().item()
+        e_out = (out.cpu().double() - ref_out).abs().max().item()
+        print(f"128^3 K3' legacy={legacy}: act err {e_act:.2e} out err {e_out:.2e}")
+        assert e_act < TOL and e_out < TOL
+        outs[legacy] = (act, out)
+    # same integers, same recombination: the two forms of K3' agree bit for bit
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    fused = _hip.conv_fused(x, b, l)
+    e_lin = (fused.cpu().double() - ref_out).abs().max().item()
+    print(f"128^3 K3L: out err {e_lin:.2e}")
+    assert e_lin < TOL
+
+
+@pytest.mark.parametrize("shape,ks,G", [
+    ((2, 1, 16, 16, 16), (9, 9, 9), 16),
+    ((1, 1, 13, 9, 72), (9, 9, 9), 16),      # ragged z/x, y > 64
+    ((1, 1, 9, 11, 132), (5, 7, 9), 7),      # kz, kx != 9: 35 kernel rows, three y tiles
+    ((2, 1, 8, 8, 64), (3, 3, 9), 4),        # 9 rows: RQ = 3 (odd), one pair step
+    ((1, 1, 10, 6, 68), (9, 5, 9), 16),      # 45 rows: RQ = 12 (even: no odd row in the tail)
+    ((1, 1, 6, 7, 64), (2, 3, 9), 3),        # 6 rows: RQ = 2, a single pair step, one quad
+    ((1, 1, 7, 5, 64), (1, 5, 9), 2),        # one z plane of the kernel
+    ((1, 1, 9, 9, 64), (1, 4, 9), 2),        # 4 rows: below the stride-4 kernel's minimum, four-copy kernel
+    ((1, 1, 12, 10, 64), (9, 9, 9), 33),     # three kernel groups: partial sums carried in `out`
+    ((1, 1, 20, 18, 64), (7, 11, 9), 5),     # 77 rows
+    ((4, 1, 32, 32, 64), (9, 9, 9), 16),     # 1 x 4 x 64 tiles, four per workgroup: waves with one round or none, ring wraps
+    ((1, 1, 64, 64, 64), (9, 9, 9), 16),     # 2 x 4 x 64 tiles, two per workgroup
+])
+def test_stride4_kernel_shapes_against_oracle_and_legacy(hip_device, shape, ks, G):
+    """ky = 9 shapes (conv_i8s.hip) against the oracle, and bit for bit against the four-copy kernel."""
+    torch.manual_seed(hash((shape, ks, G)) % 2**31)
+    occ = torch.rand(shape) < 0.3
+    bank = (torch.rand((G,) + tuple(ks)) - 0.5) * torch.logspace(-2, 0.3, G).view(G, 1, 1, 1)
+    lam = (torch.rand(G) - 0.3) / G
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    x, b, l = occ.to(hip_device), bank.to(hip_device).contiguous(), lam.to(hip_device)
+    res = {}
+    for legacy in (False, True):
+        with legacy_kernel(legacy):
+            for dt in (torch.float32, torch.float64):
+                act, out = _hip.conv_bank(x, b, l, want_act=True, want_out=True, out_dtype=dt)
+                assert (act.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item())
+                assert (out.cpu().double() - ref_out).abs().max().item() < TOL
+                res[(legacy, dt)] = (act, out)
+            _, only_out = _hip.conv_bank(x, b, l, want_act=False, want_out=True)
+            assert torch.equal(only_out, res[(legacy, torch.float32)][1])
+    for dt in (torch.float32, torch.float64):
+        assert torch.equal(res[(False, dt)][0], res[(True, dt)][0])
+        assert torch.equal(res[(False, dt)][1], res[(True, dt)][1])
+
+
+def test_stride4_kernel_full_batch_equals_legacy_bit_for_bit(hip_device):
+    """BASELINE C2's batch (32 x 64^3: eight tiles per workgroup, the halo ring wraps twice): the stride-4 kernel and the
+    four-copy kernel accumulate the same integers."""
+    torch.manual_seed(2)
+    bank, lam = _bench_bank(hip_device)
+    b, l = bank.to(hip_device).contiguous(), lam.float().to(hip_device)
+    x = torch.rand((32, 1, 64, 64, 64), device=hip_device) < 0.035
+    x[3] = True                      # one completely full tile
+    x[7] = False                     # one empty tile
+    with legacy_kernel(True):
+        a0, o0 = _hip.conv_bank(x, b, l, want_act=False, want_out=True)
+    for _ in range(3):               # and again: no dependence on launch-to-launch timing of the ring
+        a1, o1 = _hip.conv_bank(x, b, l, want_act=False, want_out=True)
+        assert torch.equal(o0, o1)
+    with legacy_kernel(True):
+        act0, _ = _hip.conv_bank(x[:8].contiguous(), b, l, want_act=True, want_out=False)
+    act1, _ = _hip.conv_bank(x[:8].contiguous(), b, l, want_act=True, want_out=False)
+    assert torch.equal(act0, act1)
+    assert o1[7].abs().max().item() == 0.0
