@@ -284,9 +284,17 @@ def main():
     vox_bytes = (24.0 * args.points + 4.0 * V) * B        # 3.449 MB/tile @ (100k, 64^3)
     conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12
     vox_gbs = vox_bytes / (vox_ms * 1e-3) / 1e9
-    # the int8 kernel issues (R*C*4 slots padded to 64-slot steps) x 3 digit planes per output instead of ntaps
-    chunks = KERNEL_SIZE[0] * KERNEL_SIZE[1] * ((KERNEL_SIZE[2] + 3) // 4)
-    i8_steps = (chunks + 15) // 16
+    # what the int8 kernel really issues per output: 64-slot MFMA steps x 3 digit planes instead of ntaps.  Stride-4
+    # kernel (conv_i8s.hip, ky = 9, 9 x 9 kernel rows): a row costs 2 1/4 dwords of K -> 183 dwords -> 12 steps;
+    # four-copy kernel (conv_i8.hip, everything else): ky padded to a multiple of 4 -> 243 dwords -> 16 steps
+    stride4 = (KERNEL_SIZE[2] == 9 and KERNEL_SIZE[0] * KERNEL_SIZE[1] == 81 and args.grid % 16 == 0
+               and not sna._hip.get_option("conv_i8_legacy"))
+    if stride4:
+        rq = (KERNEL_SIZE[0] * KERNEL_SIZE[1] + 3) // 4
+        i8_steps = rq // 2 + ((rq + 3) // 4 + 2 * (rq & 1) + 3) // 4
+    else:
+        chunks = KERNEL_SIZE[0] * KERNEL_SIZE[1] * ((KERNEL_SIZE[2] + 3) // 4)
+        i8_steps = (chunks + 15) // 16
     executed_ops = 2.0 * V * (i8_steps * 64 * 3) * 16 * B
     executed_tops = executed_ops / (conv_ms * 1e-3) / 1e12
 
@@ -440,11 +448,13 @@ def main():
                    "kernel_size": list(KERNEL_SIZE), "parallelism": f"tile-sharded x{n_gpus}, no collectives"},
         "points_per_s": B * args.points * n_gpus / (vox_ms * 1e-3),
         # dominant kernel.  `achieved` = ALGORITHMIC flops (2*V*729*16 per tile) / launch time; `peak` = dense int8
-        # MFMA peak.  `executed` counts what the kernel really issues (3 digit planes, ky padded 9 -> 12): that
-        # is the matrix-pipe utilisation figure.
-        "roofline": {"kernel": "conv_occ_i8_kernel (K3', v_mfma_i32_16x16x64_i8)", "bound": "mfma",
+        # MFMA peak.  `executed` counts what the kernel really issues (3 digit planes x 64-slot steps): that is the
+        # matrix-pipe utilisation figure.
+        "roofline": {"kernel": ("conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel") + " (K3', v_mfma_i32_16x16x64_i8)",
+                     "bound": "mfma", "mfma_steps_per_16x16_outputs": i8_steps,
                      "achieved": conv_tflops, "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s",
-                     "frac": conv_tflops / PEAK_I8_MFMA_TOPS, "traffic": traffic.get("conv_occ_i8_kernel"),
+                     "frac": conv_tflops / PEAK_I8_MFMA_TOPS,
+                     "traffic": traffic.get("conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel"),
                      "launch_ms": conv_ms, "flops_per_launch": conv_flops, "executed": executed_tops,
                      "executed_frac": executed_tops / PEAK_I8_MFMA_TOPS,
                      "executed_frac_of_measured_ceiling": executed_tops / MEASURED_I8_MFMA_TOPS},
