@@ -76,6 +76,7 @@ struct Shape {
     int32_t* route;        // out: 1 = quantisation bound exceeded, fp32 kernel takes the launch; 0 = done here
     float tol;             // bound on the worst-case activation error allowed on the int8 path (<= 0: no check)
     int stagger;           // s_sleep units (64 clocks) waves 4-7 wait once before their first round
+    int dynamic;           // rounds of a tile are claimed from an LDS ticket counter (else dealt: wave, wave + 8, ...)
     int dbg;
     RowPlan plan;
 };
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     int* landed = reinterpret_cast<int*>(bnd + 16);                              // [kNB]  waves whose DMA pieces are in
     int* done = landed + 4;                                                      // [kNB]  waves finished with the buffer
     int* flags = done + 4;                                                       // [4]    0: route, 1: a spin gave up
-    uint32_t* hbuf = reinterpret_cast<uint32_t*>(flags + 4);                     // [kNB][hdw] raw halo dwords
+    int* rclaim = flags + 4;                                                     // [kNB]  round tickets drawn per ring slot
+    uint32_t* hbuf = reinterpret_cast<uint32_t*>(rclaim + 4);                    // [kNB][hdw] raw halo dwords
     float* bank_s = reinterpret_cast<float*>(hbuf + (size_t)2 * hdw);            // [G][ntaps] (+1 pad), prologue only: over ring slot 2
                                                                                  // (first filled during tile 0's rounds) and beyond
 
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     if (lane < 8) g_i8s_w[(blockIdx.x * 8 + wave) * 8 + lane] = 0;
 #endif
     const int my_tiles = (int)blockIdx.x < s.ntiles ? (s.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    if (tid < 12) landed[tid] = 0;   // landed[0..3], done[0..3], flags[0..3]
+    if (tid < 16) landed[tid] = 0;   // landed[0..3], done[0..3], flags[0..3], rclaim[0..3]
     {   // fp32 bank -> LDS, coalesced, one batch of loads; the first two tiles' halos are requested while those loads fly
         // (the other way round the bank's loads queue behind 24 DMA pieces per wave: vmcnt retires in order) and
         // travel while the tables are built
@@ -436,9 +438,21 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             halo_dma_issue(hbuf + (size_t)bn * hdw, x, s, tile_coord(s, tile + 2 * gridDim.x), dma_lane(s, wave, lane), wave);
             dma_pending = false;
         };
-        const int k_dma = (nrounds - wave + kWaves - 1) / kWaves >= 3 ? 2 : 1;
-        int k = 0;
-        for (int round = wave; round < nrounds; round += kWaves, ++k) {
+        // Rounds are CLAIMED, not dealt: the older wave of a SIMD pair wins every tie for the matrix pipe and the issue
+        // port ([measured] dealt 4 + 4, waves 4-7 needed 10 % longer and waves 0-3 waited for them before every DMA
+        // issue; s_setprio did not move that), so whoever is ahead takes the next round of the tile.  Ring slot `bi` has
+        // seen it / kNB earlier tiles, each of which drew nrounds valid tickets and one failing ticket per wave; the
+        // next ticket is drawn a round ahead of its use.
+        const int ticket0 = (it / kNB) * (nrounds + kWaves);
+        auto claim = [&]() -> int {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&rclaim[bi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return __builtin_amdgcn_readfirstlane(t) - ticket0;
+        };
+        const int k_dma = nrounds >= 3 * kWaves ? 2 : 1;
+        int k = 0, next = 0;
+        for (int round = s.dynamic ? claim() : wave; round < nrounds; round = next, ++k) {
+            next = s.dynamic ? claim() : round + kWaves;
             const unsigned long long t_r0 = SN_WNOW();
             if (k == k_dma && dma_pending) dma_ahead();
             SN_WT(4, t_r0);
@@ -724,7 +738,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 
 size_t lds_bytes(const Shape& s) {
     const size_t hdw = (size_t)s.ZP * s.XP * DW;
-    return (size_t)s.KS * 3 * 64 * 16 + (size_t)s.NP * 4 * 8 + (size_t)s.NT * 4 * 16 + 16 + 64 + 64 + 128 + 128 + 48 +
+    return (size_t)s.KS * 3 * 64 * 16 + (size_t)s.NP * 4 * 8 + (size_t)s.NT * 4 * 16 + 16 + 64 + 64 + 128 + 128 + 64 +
            (kNB * hdw * 4 > 2 * hdw * 4 + ((size_t)s.G * s.kz * s.kx * 9 + 1) * sizeof(float)
                 ? kNB * hdw * 4 : 2 * hdw * 4 + ((size_t)s.G * s.kz * s.kx * 9 + 1) * sizeof(float)) + 16;
 }
@@ -805,6 +819,8 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     s.dbg = dbg ? atoi(dbg) : 0;
     const char* stg = getenv("SN_CONV_I8S_STAGGER");
     s.stagger = stg ? atoi(stg) : 100;   // x 64 clocks: about half a round
+    const char* stat = getenv("SN_CONV_I8S_STATIC");
+    s.dynamic = !(stat && stat[0] == '1');
     const int cus = num_cus();
     static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
     bool found = false;
