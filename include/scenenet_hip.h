@@ -187,6 +187,26 @@ int sn_voxel_desc(const double* bbox, int B, int nx, int ny, int nz, int regular
 int sn_voxel_desc_from_bounds(const double* bounds, int B, int nx, int ny, int nz,
                               double* desc, sn_stream_t stream);
 
+/* Grid descriptor in the size_x/size_y/size_z mode for a whole batch, computed on the device
+ * (replaces: pyntcloud VoxelGrid.compute with sizes, utils/pcd_processing.py:365-367, as used by
+ * core/datasets/semKITTI.py:453-455): cube the box, extend every axis by ((range // size) + 1) * size - range, n =
+ * int((max - min) / size) -- numpy's fp64 arithmetic bit for bit.  n is data dependent, so grids are allocated at a
+ * caller-given maximum (nx, ny, nz) and desc [B, SN_DESC_LEN(nx,ny,nz)] carries each tile's own edge tables: edges
+ * 0..n_a as numpy.linspace, +inf beyond.  sn_voxel_scatter / sn_gather_points take this descriptor unchanged;
+ * sn_voxel_finalize_sized keeps the voxels beyond a tile's own dims out of the column statistics and zero.
+ *   size_xyz_host  3 doubles on the host (voxel size per axis, > 0)
+ *   dims           (nullable) [B,3] i32 out: n_x, n_y, n_z of every tile
+ *   status         (nullable) [B] i32 out: 1 = the tile needs more voxels than the maximum (points beyond the table
+ *                  are dropped and counted by the scatter) */
+int sn_voxel_desc_sized(const double* bbox, int B, const double* size_xyz_host, int nx, int ny, int nz,
+                        double* desc, int32_t* dims, int32_t* status, sn_stream_t stream);
+
+/* sn_voxel_finalize for grids voxelised with a size-mode descriptor (normalize_xyz / ToFullDense over each tile's
+ * own [n_z, n_x, n_y] part of the padded grid; the rest is 0). */
+int sn_voxel_finalize_sized(const int32_t* counts, const int32_t* tower_counts, int B, int nx, int ny, int nz,
+                            const double* desc, int32_t* colstats, double* density, double* gt, float* occ,
+                            float* gt_occ, sn_stream_t stream);
+
 /* Atomic scatter: counts[b,z,x,y] += 1 per point; tower_counts (nullable) += 1
  * per point whose label equals one of keep_labels_host[0..n_keep) (<= 16).
  * Both grids [B,nz,nx,ny] i32 are zeroed by the call.

@@ -40,6 +40,8 @@ SYMBOLS = {
     "sn_voxel_bbox": (c_int, [_P, _P, _I, _P, _P]),
     "sn_voxel_desc": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "sn_voxel_desc_from_bounds": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "sn_voxel_desc_sized": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "sn_voxel_finalize_sized": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sn_voxel_scatter": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "sn_voxel_finalize": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
@@ -305,6 +307,43 @@ def voxel_desc(bbox: torch.Tensor, n_xyz: Sequence[int], regular: bool = True, f
                                   _stream())
     _check(rc, "sn_voxel_desc")
     return desc
+
+
+@_on_tensor_device
+def voxel_desc_sized(bbox: torch.Tensor, voxel_dims: Sequence[float], max_n_xyz: Sequence[int]):
+    """sn_voxel_desc_sized: size-mode descriptors of a batch on the device.  Returns (desc [B, desc_len(max)], dims
+    [B,3] i32 = (n_x, n_y, n_z) per tile, status [B] i32 = 1 where a tile needs more than the maximum)."""
+    B = bbox.shape[0]
+    nx, ny, nz = (int(v) for v in max_n_xyz)
+    dev = bbox.device
+    desc = torch.empty((B, desc_len(nx, ny, nz)), dtype=torch.float64, device=dev)
+    dims = torch.empty((B, 3), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    if len(voxel_dims) != 3:
+        raise HipLibraryError("voxel_dims must have 3 entries (size_x, size_y, size_z)")
+    sz = (ctypes.c_double * 3)(*[float(v) for v in voxel_dims])
+    rc = load().sn_voxel_desc_sized(_ptr(bbox, torch.float64, "bbox"), B, ctypes.cast(sz, c_void_p), nx, ny, nz,
+                                    _ptr(desc), _ptr(dims), _ptr(status), _stream())
+    _check(rc, "sn_voxel_desc_sized")
+    return desc, dims, status
+
+
+@_on_tensor_device
+def voxel_finalize_sized(counts, towers, desc, want_density=False, want_gt=False, want_occ=True, want_gt_occ=False):
+    """sn_voxel_finalize_sized: voxel_finalize over each tile's own part of the padded grids."""
+    B, nz, nx, ny = counts.shape
+    dev = counts.device
+    shape = (B, 1, nz, nx, ny)
+    colstats = torch.empty((B, 2, ny), dtype=torch.int32, device=dev) if (want_density or want_occ) else None
+    density = torch.empty(shape, dtype=torch.float64, device=dev) if want_density else None
+    gt = torch.empty(shape, dtype=torch.float64, device=dev) if want_gt else None
+    occ = torch.empty(shape, dtype=torch.float32, device=dev) if want_occ else None
+    gt_occ = torch.empty(shape, dtype=torch.float32, device=dev) if want_gt_occ else None
+    rc = load().sn_voxel_finalize_sized(_ptr(counts, torch.int32, "counts"), _ptr(towers, torch.int32, "towers"), B, nx,
+                                        ny, nz, _ptr(desc, torch.float64, "desc"), _ptr(colstats), _ptr(density),
+                                        _ptr(gt), _ptr(occ), _ptr(gt_occ), _stream())
+    _check(rc, "sn_voxel_finalize_sized")
+    return density, gt, occ, gt_occ
 
 
 @_on_tensor_device

@@ -247,28 +247,49 @@ class FocalTverskyLoss(TverskyLoss):
         return parent_parser
 
 
+def _dice_per_sample(predict: torch.Tensor, target: torch.Tensor, smooth, power) -> torch.Tensor:
+    """dice_loss.py:35-41: 1 - (sum(p t) + s) / (sum(p^power + t^power) + s) per sample, as torch ops on the device
+    (the branches the fused kernel does not serve: power != 2, reduction 'none')."""
+    predict = predict.contiguous().view(predict.shape[0], -1)
+    target = target.contiguous().view(target.shape[0], -1)
+    if not target.dtype.is_floating_point:
+        target = target.to(predict.dtype)
+    num = torch.sum(torch.mul(predict, target), dim=1) + smooth
+    den = torch.sum(predict.pow(power) + target.pow(power), dim=1) + smooth
+    return 1 - num / den
+
+
 class BinaryDiceLoss(torch.nn.Module):
-    """dice_loss.py:8-51 (p = 2; reduction 'mean' or 'sum')."""
+    """dice_loss.py:8-51.  p = 2 with reduction 'mean' / 'sum' (what every criterion of resolve_criterion uses) is one
+    streaming pass of csrc/loss.hip; any other power and reduction 'none' are the reference's formula in torch ops on
+    the device.  An unknown reduction raises at call time, like the reference."""
 
     def __init__(self, smooth=1, p=2, reduction="mean", **kwargs):
         super().__init__()
-        if p != 2:
-            raise NotImplementedError("BinaryDiceLoss on the HIP path is built for p = 2 (the reference's default)")
-        if reduction not in ("mean", "sum"):
-            raise NotImplementedError("BinaryDiceLoss on the HIP path: reduction 'mean' or 'sum'")
         self.smooth = smooth
         self.power = p
         self.reduction = reduction
 
     def forward(self, predict, target):
         assert predict.shape[0] == target.shape[0], "predict & target batch size don't match"
-        ranges, bin_w = _unit_tables(predict.device)
-        loss = _dense_loss(predict, target, ranges, bin_w, _hip.SN_LOSS_DICE, dice_smooth=self.smooth)
-        return loss if self.reduction == "mean" else loss * predict.shape[0]
+        if self.reduction not in ("mean", "sum", "none"):
+            raise Exception("Unexpected reduction {}".format(self.reduction))
+        if not predict.is_cuda:
+            raise _hip.HipLibraryError("BinaryDiceLoss runs on the HIP device only (no CPU path): move predict to cuda")
+        if self.power == 2 and self.reduction != "none":
+            ranges, bin_w = _unit_tables(predict.device)
+            loss = _dense_loss(predict, target, ranges, bin_w, _hip.SN_LOSS_DICE, dice_smooth=self.smooth)
+            return loss if self.reduction == "mean" else loss * predict.shape[0]
+        loss = _dice_per_sample(predict, target, self.smooth, self.power)
+        if self.reduction == "mean":
+            return loss.mean()
+        return loss.sum() if self.reduction == "sum" else loss
 
 
 class BinaryDiceLoss_BCE(WeightedMSE):
-    """dice_loss.py:55-95: weights * BCELoss + BinaryDiceLoss, one pass over (pred, gt).  reduction 'mean' or 'sum'."""
+    """dice_loss.py:55-95: weights * BCELoss + BinaryDiceLoss.  'mean' / 'sum': one pass over (pred, gt) in
+    csrc/loss.hip; 'none': the reference's expression in torch ops (per-element weighted BCE plus the per-sample dice
+    vector, with whatever torch's broadcasting makes of that sum)."""
 
     def __init__(self, targets=None, weighting_scheme_path=HIST_PATH, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
                  reduction="mean", **kwargs) -> None:
@@ -277,6 +298,13 @@ class BinaryDiceLoss_BCE(WeightedMSE):
         self.reduction = reduction
 
     def forward(self, predict, target):
+        if self.reduction not in ("mean", "sum", "none"):
+            raise Exception("Unexpected reduction {}".format(self.reduction))
+        if self.reduction == "none":
+            tgt = target if target.dtype.is_floating_point else target.to(predict.dtype)
+            weights = self.get_weight_target(tgt).to(predict.device)
+            bce = torch.nn.functional.binary_cross_entropy(predict, tgt.to(predict.dtype), reduction="none")
+            return weights * bce + self.dice(predict, target)
         ranges, bin_w = self._device_tables(predict.device)
         if self.reduction == "mean":   # mean(w * bce) + mean_b(dice_b)
             return _dense_loss(predict, target, ranges, bin_w, _hip.SN_LOSS_WBCE | _hip.SN_LOSS_DICE,
@@ -356,21 +384,20 @@ class GENEO_Dice_Loss(GENEO_Loss):
 
 
 class GENEO_Dice_BCE(GENEO_Loss):
-    """geneo_loss.py:110-128: mse_weight * (weights * BCE + dice) + penalties.  (The reference's constructor passes
-    its arguments to BinaryDiceLoss_BCE in the wrong positions and raises a TypeError; this is the evident intent.)"""
+    """geneo_loss.py:110-128: mse_weight * (weights * BCE + dice) + penalties, reduction 'mean' / 'sum' / 'none' as in
+    BinaryDiceLoss_BCE.  (The reference's constructor passes its arguments to BinaryDiceLoss_BCE in the wrong
+    positions and raises a TypeError; this is the evident intent.)"""
 
     def __init__(self, targets=None, weighting_scheme_path=None, weight_alpha=1, weight_epsilon=0.1, mse_weight=1,
                  convex_weight=1, reduction="mean", **kwargs) -> None:
         super().__init__(targets, weighting_scheme_path, weight_alpha, weight_epsilon, mse_weight, convex_weight,
                          **kwargs)
-        if reduction != "mean":
-            raise NotImplementedError("GENEO_Dice_BCE on the HIP path: reduction 'mean'")
-        self.dice = BinaryDiceLoss()
+        self.reduction = reduction
+        self.dice = BinaryDiceLoss(reduction=reduction)
 
     def forward(self, y_pred, y_gt, cvx_coeffs, geneo_params):
-        ranges, bin_w = self._device_tables(y_pred.device)
-        dense = _dense_loss(y_pred, y_gt, ranges, bin_w, _hip.SN_LOSS_WBCE | _hip.SN_LOSS_DICE,
-                            dice_smooth=self.dice.smooth)
+        # the same three reductions as BinaryDiceLoss_BCE.forward, on this object's own weighting tables
+        dense = BinaryDiceLoss_BCE.forward(self, y_pred, y_gt)
         return self.mse_weight * dense + self._penalties(cvx_coeffs, geneo_params)
 
 

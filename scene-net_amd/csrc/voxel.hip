@@ -281,6 +281,72 @@ __global__ void desc_kernel(const double* __restrict__ box, int nparts, int nx, 
     }
 }
 
+// ---------------------------------------------------------------- grid descriptor, size_x / size_y / size_z mode
+// pyntcloud VoxelGrid.compute with sizes (utils/pcd_processing.py:365-367, core/datasets/semKITTI.py:453-455): the box
+// is cubed, every axis is then extended by m = ((range // size) + 1) * size - range (range = the ORIGINAL extent of
+// that axis) and gets n = int((max - min) / size) voxels -- n is data dependent, so a batch is voxelised into grids of
+// a caller-given maximum (nx, ny, nz) and the descriptor carries each tile's own table: edges 0..n_a are
+// numpy.linspace(lo, hi, n_a + 1) bit for bit, edges beyond are +inf (no point is ever above them, so the binning,
+// scatter and gather kernels run unchanged on the padded table; a row / column of the grid is REAL iff its upper edge
+// is finite).  dims (nullable) [B,3] i32 receives (n_x, n_y, n_z); status (nullable) [B] i32 is 1 where a tile needs
+// more voxels than the maximum (its points beyond the table are dropped and counted in `dropped`).
+struct Vec3s { double v[3]; };
+// numpy's floor_divide for positive doubles (npy_divmod): fmod is exact, the quotient of (a - mod) by b is rounded to
+// the nearest integer
+__device__ __forceinline__ double np_floor_divide(double a, double b) {
+    const double mod = fmod(a, b);
+    const double div = __ddiv_rn(__dsub_rn(a, mod), b);
+    if (div == 0.0) return 0.0;
+    double fl = floor(div);
+    if (__dsub_rn(div, fl) > 0.5) fl = __dadd_rn(fl, 1.0);
+    return fl;
+}
+__global__ void desc_sized_kernel(const double* __restrict__ box, Vec3s size, int nx, int ny, int nz,
+                                  double* __restrict__ desc, int32_t* __restrict__ dims,
+                                  int32_t* __restrict__ status) {
+    const int b = blockIdx.x;
+    double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+    const double* bb = box + (size_t)b * 6;
+    double lo[3], hi[3], r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = bb[c];
+        hi[c] = bb[3 + c];
+        r[c] = __dsub_rn(hi[c], lo[c]);
+    }
+    const double rmax = fmax(r[0], fmax(r[1], r[2]));
+    const int nmax[3] = {nx, ny, nz};
+    int n[3];
+    bool over = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double half = __ddiv_rn(__dsub_rn(rmax, r[c]), 2.0);   // regular_bounding_box: the cube
+        lo[c] = __dsub_rn(lo[c], half);
+        hi[c] = __dadd_rn(hi[c], half);
+        const double m = __dsub_rn(__dmul_rn(__dadd_rn(np_floor_divide(r[c], size.v[c]), 1.0), size.v[c]), r[c]);
+        const double mh = __ddiv_rn(m, 2.0);
+        lo[c] = __dsub_rn(lo[c], mh);
+        hi[c] = __dadd_rn(hi[c], mh);
+        n[c] = (int)__ddiv_rn(__dsub_rn(hi[c], lo[c]), size.v[c]);   // int(): truncation
+        over |= n[c] > nmax[c];
+    }
+    if (threadIdx.x < 3) {
+        d[threadIdx.x] = lo[threadIdx.x];
+        d[3 + threadIdx.x] = hi[threadIdx.x];
+        if (dims) dims[b * 3 + threadIdx.x] = n[threadIdx.x];
+    }
+    if (status && threadIdx.x == 0) status[b] = over ? 1 : 0;
+    int base = 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double step = __ddiv_rn(__dsub_rn(hi[c], lo[c]), (double)n[c]);
+        for (int k = threadIdx.x; k <= nmax[c]; k += blockDim.x)
+            d[base + k] = (k > n[c]) ? __longlong_as_double(0x7ff0000000000000ll)
+                                     : (k == n[c]) ? hi[c] : __dadd_rn(__dmul_rn((double)k, step), lo[c]);
+        base += nmax[c] + 1;
+    }
+}
+
 // The descriptor of tile b from its partial boxes, written by the calling workgroup (nthreads threads, >= 64) into
 // `lohi` [6] and `edges` [nx+ny+nz+3] (LDS or global) -- the same instruction sequence as desc_kernel, so every
 // workgroup that derives it gets the same bits.  Ends with a __syncthreads().
@@ -367,12 +433,14 @@ struct Binner {
     __device__ __forceinline__ void init(const double* edges, const double* d, int nx_, int ny_, int nz_) {
         ex = edges; ey = edges + nx_ + 1; ez = edges + nx_ + ny_ + 2;
         nx = nx_; ny = ny_; nz = nz_;
-        const int n[3] = {nx_, ny_, nz_};
+        // the guess only needs the bin width: the first step of each edge table (== (hi - lo) / n up to rounding, and
+        // right for the padded per-tile tables of the size mode, whose real n is not the table's)
+        const double* e[3] = {ex, ey, ez};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             lo[a] = d[a];
-            double step = (d[3 + a] - d[a]) / (double)n[a];
-            inv[a] = (step > 0.0) ? 1.0 / step : 0.0;
+            const double step = e[a][1] - e[a][0];
+            inv[a] = (step > 0.0 && step < DBL_MAX) ? 1.0 / step : 0.0;
         }
     }
     // flat [z][x][y] index, or -1 when the point is NaN / outside the edge table (np.clip to n).
@@ -675,11 +743,19 @@ __global__ void colstats_init_kernel(int32_t* cs, int B, int ny) {
 
 // grid (S, B): block s takes rows r = s, s+S, ... of the [nz*nx, ny] count matrix of tile b;
 // threads run along y (coalesced), kThreads/ny' row lanes deep.
+// desc (nullable): size-mode descriptor -- rows (z, x) beyond the tile's own dims are not part of its grid and stay out
+// of the column statistics (a row is real iff the upper edges of its z and x bins are finite).
+__device__ __forceinline__ bool real_row(const double* __restrict__ d, int nx, int ny, int r) {
+    const int z = r / nx, x = r - z * nx;
+    return d[6 + x + 1] < DBL_MAX && d[6 + nx + 1 + ny + 1 + z + 1] < DBL_MAX;
+}
 __global__ __launch_bounds__(kThreads) void colstats_kernel(const int32_t* __restrict__ counts, int rows, int ny,
                                                             int32_t* __restrict__ cs,
-                                                            const int32_t* __restrict__ gate) {
+                                                            const int32_t* __restrict__ gate,
+                                                            const double* __restrict__ desc, int nx, int desc_len) {
     const int b = blockIdx.y;
     if (gate && !gate[b]) return;
+    const double* d = desc ? desc + (size_t)b * desc_len : nullptr;
     const int32_t* c = counts + (size_t)b * rows * ny;
     for (int y0 = 0; y0 < ny; y0 += kThreads) {
         const int width = min(ny - y0, kThreads);
@@ -688,6 +764,7 @@ __global__ __launch_bounds__(kThreads) void colstats_kernel(const int32_t* __res
         if (tr >= depth) continue;
         int mn = INT_MAX, mx = 0;
         for (int r = blockIdx.x * depth + tr; r < rows; r += gridDim.x * depth) {
+            if (d && !real_row(d, nx, ny, r)) continue;
             int v = c[(size_t)r * ny + y0 + ty];
             mn = min(mn, v);
             mx = max(mx, v);
@@ -706,13 +783,23 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ cs, size_t V, int ny,
                                                             double* __restrict__ density, double* __restrict__ gt,
                                                             OT* __restrict__ occ, OT* __restrict__ gt_occ,
-                                                            const int32_t* __restrict__ gate) {
+                                                            const int32_t* __restrict__ gate,
+                                                            const double* __restrict__ desc, int nx, int desc_len) {
     const int b = blockIdx.y;
     if (gate && !gate[b]) return;
+    const double* d = desc ? desc + (size_t)b * desc_len : nullptr;
     const size_t stride = (size_t)gridDim.x * kThreads;
     for (size_t v = (size_t)blockIdx.x * kThreads + threadIdx.x; v < V; v += stride) {
         const size_t i = (size_t)b * V + v;
         const int y = (int)(v % ny);
+        if (d && !(real_row(d, nx, ny, (int)(v / ny)) && d[6 + nx + 1 + y + 1] < DBL_MAX)) {
+            // a voxel beyond this tile's own dims (size mode: grids are allocated at the batch maximum): not part of the grid
+            if (density) density[i] = 0.0;
+            if (occ) occ[i] = (OT)0;
+            if (gt) gt[i] = 0.0;
+            if (gt_occ) gt_occ[i] = (OT)0;
+            continue;
+        }
         const int c = counts[i];
         if (density || occ) {
             // sklearn MinMaxScaler: scale = 1/range (range < 10 eps -> 1); X*scale + (0 - min*scale)
@@ -809,20 +896,23 @@ void launch_scatter(const double* pts, const double* labels, const int64_t* offs
 
 template <typename OT>
 void launch_finalize(const int32_t* counts, const int32_t* towers, int B, int nx, int ny, int nz, int32_t* colstats,
-                     double* density, double* gt, OT* occ, OT* gt_occ, const int32_t* gate, hipStream_t s) {
+                     double* density, double* gt, OT* occ, OT* gt_occ, const int32_t* gate, hipStream_t s,
+                     const double* desc = nullptr) {
     const size_t V = (size_t)nx * ny * nz;
+    const int dlen = SN_DESC_LEN(nx, ny, nz);
     if (density || occ) {
         hipLaunchKernelGGL(colstats_init_kernel, dim3((B * 2 * ny + 255) / 256), dim3(256), 0, s, colstats, B, ny);
         const int rows = nz * nx;
         int S = (rows + 63) / 64;
         if (S > 64) S = 64;
-        hipLaunchKernelGGL(colstats_kernel, dim3(S, B), dim3(kThreads), 0, s, counts, rows, ny, colstats, gate);
+        hipLaunchKernelGGL(colstats_kernel, dim3(S, B), dim3(kThreads), 0, s, counts, rows, ny, colstats, gate, desc, nx,
+                           dlen);
     }
     size_t blocks = (V + kThreads - 1) / kThreads;
     const size_t cap = (size_t)blocks_per_tile(B, 4096);
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(finalize_kernel<OT>, dim3((unsigned)blocks, B), dim3(kThreads), 0, s, counts, towers, colstats,
-                       V, ny, density, gt, occ, gt_occ, gate);
+                       V, ny, density, gt, occ, gt_occ, gate, desc, nx, dlen);
 }
 
 }  // namespace
@@ -860,6 +950,37 @@ extern "C" int sn_voxel_desc(const double* bbox, int B, int nx, int ny, int nz, 
 extern "C" int sn_voxel_desc_from_bounds(const double* bounds, int B, int nx, int ny, int nz, double* desc,
                                          sn_stream_t stream) {
     return desc_common(bounds, B, nx, ny, nz, 0, 1, desc, stream, "sn_voxel_desc_from_bounds");
+}
+
+extern "C" int sn_voxel_desc_sized(const double* bbox, int B, const double* size_xyz_host, int nx, int ny, int nz,
+                                   double* desc, int32_t* dims, int32_t* status, sn_stream_t stream) {
+    if (!bbox || !desc || !size_xyz_host) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_desc_sized: null pointer");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_desc_sized: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny, nz);
+    Vec3s sz;
+    for (int c = 0; c < 3; ++c) {
+        sz.v[c] = size_xyz_host[c];
+        if (!(sz.v[c] > 0.0)) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_desc_sized: voxel size must be > 0");
+    }
+    hipLaunchKernelGGL(desc_sized_kernel, dim3(B), dim3(128), 0, sn::as_stream(stream), bbox, sz, nx, ny, nz, desc, dims,
+                       status);
+    return sn::check_launch("sn_voxel_desc_sized");
+}
+
+extern "C" int sn_voxel_finalize_sized(const int32_t* counts, const int32_t* tower_counts, int B, int nx, int ny, int nz,
+                                       const double* desc, int32_t* colstats, double* density, double* gt, float* occ,
+                                       float* gt_occ, sn_stream_t stream) {
+    if (!counts || !desc) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_finalize_sized: null counts or desc");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_finalize_sized: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny,
+                        nz);
+    if ((gt || gt_occ) && !tower_counts)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_finalize_sized: gt outputs need tower_counts");
+    if ((density || occ) && !colstats)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_finalize_sized: density/occ need the colstats workspace");
+    launch_finalize<float>(counts, tower_counts, B, nx, ny, nz, colstats, density, gt, occ, gt_occ, nullptr,
+                           sn::as_stream(stream), desc);
+    return sn::check_launch("sn_voxel_finalize_sized");
 }
 
 extern "C" int sn_voxel_prepare(const double* pts, const int64_t* offsets, int B, int nx, int ny, int nz,

@@ -73,6 +73,8 @@ class VoxelGrids:
     desc: torch.Tensor                   # [B, 6+nx+ny+nz+3] f64: lo, hi, edges
     dropped: torch.Tensor                # [B] i32
     flags: Optional[torch.Tensor] = None  # [B] i32, occupancy path: tiles redone by the counting kernels
+    dims: Optional[torch.Tensor] = None   # [B,3] i32 (n_x, n_y, n_z) per tile -- voxel-size mode: grids are padded to the maximum
+    status: Optional[torch.Tensor] = None  # [B] i32, voxel-size mode: 1 = the tile needs more voxels than the maximum
 
 
 def _labels_list(tower_label) -> List[float]:
@@ -83,17 +85,38 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
                    keep_labels: Optional[Sequence[float]] = None, want_density: bool = False,
                    want_gt: bool = False, want_occ: bool = True, want_gt_occ: bool = False,
                    bounds: Optional[torch.Tensor] = None, want_counts: bool = False,
-                   occ_dtype: torch.dtype = torch.float32) -> VoxelGrids:
-    """n_x/n_y/n_z mode of voxelize_ply for a whole batch.  `voxelgrid_dims` is (x, y, z) like the
-    reference (pcd_processing.py:362-363); grids come back [.., nz, nx, ny] (voxelization.py:193).
+                   occ_dtype: torch.dtype = torch.float32,
+                   voxel_dims: Optional[Sequence[float]] = None) -> VoxelGrids:
+    """voxelize_ply for a whole batch.  `voxelgrid_dims` is (x, y, z) like the reference
+    (pcd_processing.py:362-363); grids come back [.., nz, nx, ny] (voxelization.py:193).
 
-    When only the binary grids are wanted (what SceneNet consumes) and the tile's bitmap fits LDS, the
-    occupancy kernels run (LDS atomics, no global atomics); the density / ratio / count outputs take the
-    counting kernels."""
+    n_x/n_y/n_z mode (voxel_dims None): when only the binary grids are wanted (what SceneNet consumes) and the tile's
+    bitmap fits LDS, the occupancy kernels run (LDS atomics, no global atomics); the density / ratio / count outputs
+    take the counting kernels.
+
+    Voxel-size mode (`voxel_dims` = (size_x, size_y, size_z), pcd_processing.py:365-367, semKITTI.py:453-455): every
+    tile's grid extents follow from its own bounding box, so `voxelgrid_dims` is the MAXIMUM the grids are allocated
+    at; each tile's (n_x, n_y, n_z) is computed on the device (no host round trip) and returned in `.dims`, voxels
+    beyond a tile's own dims are 0, `.status[b]` = 1 flags a tile that would need more than the maximum."""
     nx, ny, nz = (int(v) for v in voxelgrid_dims)
     want_t = (want_gt or want_gt_occ)
     if want_t and (batch.labels is None or keep_labels is None):
         raise ValueError("ground-truth grids need labels and keep_labels")
+    if voxel_dims is not None:
+        if bounds is not None:
+            raise ValueError("voxel_dims and bounds are mutually exclusive")
+        bbox = _hip.voxel_bbox(batch.pts, batch.offsets)
+        desc, dims, status = _hip.voxel_desc_sized(bbox, voxel_dims, (nx, ny, nz))
+        counts, towers, dropped = _hip.voxel_scatter(batch.pts, batch.labels if want_t else None, batch.offsets, desc,
+                                                     (nx, ny, nz), _labels_list(keep_labels) if want_t else (),
+                                                     want_towers=want_t)
+        density, gt, occ, gt_occ = _hip.voxel_finalize_sized(counts, towers, desc, want_density, want_gt, want_occ,
+                                                             want_gt_occ)
+        if occ is not None and occ_dtype != torch.float32:
+            occ = occ.to(occ_dtype)
+        if gt_occ is not None and occ_dtype != torch.float32:
+            gt_occ = gt_occ.to(occ_dtype)
+        return VoxelGrids(counts, towers, density, gt, occ, gt_occ, desc, dropped, None, dims, status)
     occupancy_only = (want_occ and not (want_density or want_gt or want_counts)
                       and _hip.occupancy_supported((nx, ny, nz), 2 if want_gt_occ else 1))
     if occupancy_only and bounds is None:   # the hot path: bbox, descriptor, bitmap, expansion in four launches

@@ -376,7 +376,56 @@ def dump_loss():
     print("geneo_loss.npz:", list(cases))
 
 
+def dump_loss_extra():
+    """The criterion branches round 1 left out: BinaryDiceLoss with p != 2 and every reduction
+    (core/criterions/dice_loss.py:33-51), BinaryDiceLoss_BCE with reduction='none' (:88-89; its `weights*bce + dice`
+    only broadcasts for a batch of one).  Values and gradients w.r.t. the prediction, from the reference's classes."""
+    import tempfile
+    from core.criterions.dice_loss import BinaryDiceLoss, BinaryDiceLoss_BCE
+    out = {}
+    shapes = {"b3": (3, 1, 6, 8, 8), "b1": (1, 1, 8, 8, 16)}
+    for si, (sname, shape) in enumerate(shapes.items()):
+        g = torch.Generator().manual_seed(500 + si)
+        for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            gt = (torch.rand(shape, generator=g, dtype=torch.float64) < 0.1).to(dt)
+            pred0 = torch.rand(shape, generator=g, dtype=torch.float64).clamp(1e-4, 1 - 1e-4).to(dt)
+            out[f"{sname}_{dt_name}|pred"] = pred0.numpy()
+            out[f"{sname}_{dt_name}|gt"] = gt.numpy()
+            for p_ in (1, 2, 3):
+                for red in ("mean", "sum", "none"):
+                    for smooth in (1, 0.5):
+                        crit = BinaryDiceLoss(smooth=smooth, p=p_, reduction=red)
+                        pred = pred0.clone().requires_grad_(True)
+                        loss = crit(pred, gt)
+                        loss.sum().backward()
+                        key = f"{sname}_{dt_name}|dice_p{p_}_{red}_s{smooth}"
+                        out[key + "|loss"] = loss.detach().numpy()
+                        out[key + "|grad_pred"] = pred.grad.numpy()
+            if sname == "b1":
+                cwd = os.getcwd()
+                with tempfile.TemporaryDirectory() as tmp:
+                    os.chdir(tmp)
+                    try:
+                        crit = BinaryDiceLoss_BCE(targets=gt, weighting_scheme_path=None, reduction="none",
+                                                  weight_alpha=0.5, weight_epsilon=0.2)
+                        crit.freqs = torch.tensor([40, 3, 5, 7, 9, 2, 4, 6, 8, 11], dtype=torch.int64)
+                        pred = pred0.clone().requires_grad_(True)
+                        loss = crit(pred, gt)
+                        loss.sum().backward()
+                        out[f"{sname}_{dt_name}|dice_bce_none|loss"] = loss.detach().numpy()
+                        out[f"{sname}_{dt_name}|dice_bce_none|grad_pred"] = pred.grad.numpy()
+                        out[f"{sname}_{dt_name}|dice_bce_none|freqs"] = crit.freqs.numpy()
+                        out[f"{sname}_{dt_name}|dice_bce_none|ranges"] = crit.ranges.numpy()
+                    finally:
+                        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "geneo_loss_extra.npz"), **out)
+    print("geneo_loss_extra.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["loss_extra"]:
+        dump_loss_extra()
+        sys.exit(0)
     if sys.argv[1:] == ["loss"]:
         dump_loss()
         sys.exit(0)
@@ -384,6 +433,7 @@ if __name__ == "__main__":
         dump_vxg_to_xyz()
         sys.exit(0)
     dump_loss()
+    dump_loss_extra()
     dump_real_tile_subset()
     dump_vxg_to_xyz()
     dump_voxel_normalize()

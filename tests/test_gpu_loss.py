@@ -243,3 +243,68 @@ def test_cabi_rejects_bad_arguments(hip_device):
         _hip.loss_forward(pred, gt, ranges, torch.ones(10, device=hip_device), 0)
     with pytest.raises(sna.HipLibraryError, match="HIP device"):
         _hip.loss_forward(pred.cpu(), gt.cpu(), ranges, torch.ones(10, device=hip_device), 1)
+
+
+# ------------------------------------------------------------------ the criterion branches of VERDICT r1 #8
+EXTRA = np.load(os.path.join(os.path.dirname(__file__), "golden", "geneo_loss_extra.npz"))
+
+
+@pytest.mark.parametrize("red", ["mean", "sum", "none"])
+@pytest.mark.parametrize("p", [1, 2, 3])
+@pytest.mark.parametrize("case", ["b3_f32", "b3_f64", "b1_f64"])
+def test_binary_dice_every_power_and_reduction(hip_device, case, p, red):
+    """BinaryDiceLoss(p, reduction) against the reference's own values and gradients (dice_loss.py:33-51)."""
+    for smooth in (1, 0.5):
+        crit = sna.BinaryDiceLoss(smooth=smooth, p=p, reduction=red)
+        pred = torch.from_numpy(EXTRA[f"{case}|pred"]).to(hip_device).requires_grad_(True)
+        gt = torch.from_numpy(EXTRA[f"{case}|gt"]).to(hip_device)
+        loss = crit(pred, gt)
+        loss.sum().backward()
+        key = f"{case}|dice_p{p}_{red}_s{smooth}"
+        ref, gref = EXTRA[key + "|loss"], EXTRA[key + "|grad_pred"]
+        tol = _tol(pred.dtype)
+        assert loss.shape == ref.shape
+        assert np.abs(loss.detach().cpu().numpy() - ref).max() <= tol * np.abs(ref).max()
+        assert np.abs(pred.grad.cpu().numpy() - gref).max() <= tol * np.abs(gref).max()
+    # binary occupancy targets (torch.bool, what ToFullDense yields on the device) give the same numbers
+    crit = sna.BinaryDiceLoss(p=p, reduction=red)
+    pred = torch.from_numpy(EXTRA[f"{case}|pred"]).to(hip_device)
+    gt = torch.from_numpy(EXTRA[f"{case}|gt"]).to(hip_device)
+    a, b = crit(pred, gt), crit(pred, gt.bool())
+    assert torch.allclose(a, b, rtol=1e-6, atol=0)
+    with pytest.raises(Exception, match="Unexpected reduction"):
+        sna.BinaryDiceLoss(reduction="median")(pred, gt)
+
+
+@pytest.mark.parametrize("case", ["b1_f32", "b1_f64"])
+def test_dice_bce_reduction_none(hip_device, case):
+    """BinaryDiceLoss_BCE(reduction='none') and GENEO_Dice_BCE in all three reductions."""
+    gt = torch.from_numpy(EXTRA[f"{case}|gt"])
+    freqs = torch.from_numpy(EXTRA[f"{case}|dice_bce_none|freqs"])
+    crit = sna.BinaryDiceLoss_BCE(targets=gt, weighting_scheme_path=None, save_weighting_scheme=False, reduction="none",
+                                  weight_alpha=0.5, weight_epsilon=0.2)
+    crit.freqs = freqs.to(hip_device)
+    pred = torch.from_numpy(EXTRA[f"{case}|pred"]).to(hip_device).requires_grad_(True)
+    loss = crit(pred, gt.to(hip_device))
+    loss.sum().backward()
+    ref, gref = EXTRA[f"{case}|dice_bce_none|loss"], EXTRA[f"{case}|dice_bce_none|grad_pred"]
+    tol = _tol(pred.dtype)
+    assert loss.shape == ref.shape
+    assert np.abs(loss.detach().cpu().numpy() - ref).max() <= tol * np.abs(ref).max()
+    assert np.abs(pred.grad.cpu().numpy() - gref).max() <= tol * np.abs(gref).max()
+    # GENEO_Dice_BCE = mse_weight * BinaryDiceLoss_BCE + penalties, in every reduction
+    cvx = torch.nn.ParameterDict({"lambda_a": torch.nn.Parameter(torch.tensor(-0.2)),
+                                  "lambda_b": torch.nn.Parameter(torch.tensor(1.2), requires_grad=False)}).to(hip_device)
+    gp = torch.nn.ParameterDict({"r": torch.nn.Parameter(torch.tensor(-0.5))}).to(hip_device)
+    for red in ("mean", "sum", "none"):
+        g = sna.GENEO_Dice_BCE(targets=gt, weighting_scheme_path=None, save_weighting_scheme=False, reduction=red,
+                               weight_alpha=0.5, weight_epsilon=0.2, mse_weight=3.0, convex_weight=2.0)
+        g.freqs = freqs.to(hip_device)
+        d = sna.BinaryDiceLoss_BCE(targets=gt, weighting_scheme_path=None, save_weighting_scheme=False, reduction=red,
+                                   weight_alpha=0.5, weight_epsilon=0.2)
+        d.freqs = freqs.to(hip_device)
+        p2 = pred.detach()
+        want = 3.0 * d(p2, gt.to(hip_device)) + 2.0 * (0.2 + 0.0) + 2.0 * 0.5   # relu(-lambda_a), relu(-(1 - lambda_a)), relu(-r)
+        got = g(p2, gt.to(hip_device), cvx, gp)
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, rtol=1e-6, atol=0), red

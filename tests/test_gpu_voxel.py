@@ -241,3 +241,92 @@ def test_vxg_to_xyz_bit_exact(golden_dir, hip_device):
         assert got.is_cuda and np.array_equal(got.cpu().numpy(), vo.vxg_to_xyz(g, origin, size)), dt
     with pytest.raises(ValueError):
         sna.vxg_to_xyz(np.zeros((4, 4)))
+
+
+# ------------------------------------------------------------------ voxel-size mode for whole batches (C4)
+def _velodyne_scan(seed, n=120_000):
+    """A SemanticKITTI-shaped scan: a disc of ground returns thinning with range, verticals, in the sensor frame."""
+    rng = np.random.default_rng(seed)
+    r = 2.0 + 48.0 * rng.random(n) ** 1.7
+    a = rng.random(n) * 2 * np.pi
+    z = -1.7 + 0.02 * r * rng.standard_normal(n)
+    wall = rng.random(n) < 0.25
+    z[wall] = -1.7 + rng.random(wall.sum()) * rng.choice([2.0, 4.0, 8.0], wall.sum())
+    pts = np.stack([r * np.cos(a), r * np.sin(a), z], axis=1)
+    labels = np.where(wall & (rng.random(n) < 0.1), 80.0, 40.0)   # 80 = pole
+    return pts, labels
+
+
+def test_size_mode_batch_on_device_against_oracle(hip_device):
+    """voxelize_batch(voxel_dims=...): per-tile grid extents computed on the device (no host round trip), grids
+    padded to a maximum -- counts, density, ratio, dims and the per-point read-back against the oracle."""
+    tiles, labels = zip(*[_velodyne_scan(50 + i, 30_000 + 7_000 * i) for i in range(3)])
+    # different extents per tile: scale the scans differently
+    tiles = [t * s for t, s in zip(tiles, (1.0, 0.55, 0.8))]
+    vox = (1.7, 1.9, 1.6)   # the box is cubed first (regular_bounding_box), so every axis spans the largest extent
+    maxd = (64, 64, 64)
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    g = sna.voxelize_batch(batch, maxd, [80.0], want_density=True, want_gt=True, want_occ=True, want_gt_occ=True,
+                           voxel_dims=vox)
+    assert g.status.cpu().tolist() == [0, 0, 0] and g.dropped.cpu().tolist() == [0, 0, 0]
+    seen = set()
+    for b in range(3):
+        counts, towers, gv = vo.voxel_counts(tiles[b], None, vox, labels[b], [80.0])
+        nx, ny, nz = (int(v) for v in gv["x_y_z"])
+        seen.add((nx, ny, nz))
+        assert g.dims[b].cpu().tolist() == [nx, ny, nz]
+        assert max(nx, ny, nz) <= 64
+        c = g.counts[b].cpu().numpy()
+        assert np.array_equal(c[:nz, :nx, :ny], counts) and c.sum() == counts.sum()      # nothing outside the tile's part
+        assert np.array_equal(g.towers[b].cpu().numpy()[:nz, :nx, :ny], towers)
+        dens = vo.normalize_xyz(counts.astype(np.float64))
+        d = g.density[b, 0].cpu().numpy()
+        assert np.array_equal(d[:nz, :nx, :ny], dens) and np.count_nonzero(d) == np.count_nonzero(dens)
+        ratio = np.zeros(counts.shape)
+        ratio[counts > 0] = towers[counts > 0] / counts[counts > 0]
+        assert np.array_equal(g.gt[b, 0].cpu().numpy()[:nz, :nx, :ny], ratio)
+        assert np.array_equal(g.occ[b, 0].cpu().numpy()[:nz, :nx, :ny], vo.to_full_dense(dens))
+        # every edge of the tile's own tables, bit for bit; +inf beyond
+        e = g.desc[b].cpu().numpy()
+        ex, ey, ez = e[6:6 + 65], e[6 + 65:6 + 130], e[6 + 130:6 + 195]
+        for got, want, n in ((ex, gv["segments"][0], nx), (ey, gv["segments"][1], ny), (ez, gv["segments"][2], nz)):
+            assert np.array_equal(got[:n + 1], want) and np.all(np.isinf(got[n + 1:]))
+    assert len(seen) > 1   # the tiles really have different grids
+    # per-point read-back of a grid through the same descriptor
+    vals = torch.arange(3 * 64 ** 3, dtype=torch.float32, device=hip_device).reshape(3, 1, 64, 64, 64)
+    got = _hip.gather_points(vals, batch.pts, batch.offsets, g.desc)[0].cpu().numpy()
+    o = 0
+    for b in range(3):
+        gv = vo._voxelize(tiles[b], None, vox)
+        flat = b * 64 ** 3 + (gv["voxel_z"] * 64 + gv["voxel_x"]) * 64 + gv["voxel_y"]
+        assert np.array_equal(got[o:o + len(flat)], flat.astype(np.float32))
+        o += len(flat)
+    # a maximum that is too small is reported, not silently wrong
+    g2 = sna.voxelize_batch(batch, (16, 16, 16), voxel_dims=vox, want_counts=True)
+    assert g2.status.cpu().tolist()[0] == 1 and g2.dropped[0].item() > 0
+
+
+def test_size_mode_128_cubed_velodyne_scans_full_size(hip_device):
+    """BASELINE C4's shape: 120k-point scans into 128^3-capacity grids with a fixed voxel size; counts and the per-point
+    gather against the oracle at full size."""
+    tiles, labels = zip(*[_velodyne_scan(7 + i) for i in range(4)])
+    vox = (0.8, 0.85, 0.8)   # ~100 m cube -> about 125 x 118 x 125 voxels
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    g = sna.voxelize_batch(batch, (128, 128, 128), [80.0], want_occ=True, want_gt_occ=True, want_counts=True,
+                           voxel_dims=vox, occ_dtype=torch.bool)
+    assert g.status.sum().item() == 0 and g.dropped.sum().item() == 0
+    pred = torch.rand((4, 1, 128, 128, 128), device=hip_device)
+    got = _hip.gather_points(pred, batch.pts, batch.offsets, g.desc)[0].cpu().numpy()
+    o = 0
+    for b in range(4):
+        counts, towers, gv = vo.voxel_counts(tiles[b], None, vox, labels[b], [80.0])
+        nx, ny, nz = (int(v) for v in gv["x_y_z"])
+        assert g.dims[b].cpu().tolist() == [nx, ny, nz] and max(nx, ny, nz) <= 128
+        assert np.array_equal(g.counts[b].cpu().numpy()[:nz, :nx, :ny], counts)
+        assert g.counts[b].sum().item() == len(tiles[b])
+        occ = vo.to_full_dense(vo.normalize_xyz(counts.astype(np.float64))) > 0
+        assert np.array_equal(g.occ[b, 0].cpu().numpy()[:nz, :nx, :ny], occ)
+        assert np.array_equal(g.gt_occ[b, 0].cpu().numpy()[:nz, :nx, :ny], towers > 0)
+        want = pred[b, 0].cpu().numpy()[gv["voxel_z"], gv["voxel_x"], gv["voxel_y"]]
+        assert np.array_equal(got[o:o + len(want)], want)
+        o += len(want)
