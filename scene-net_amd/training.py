@@ -3,9 +3,15 @@ into a hipGraph and replayed.
 
 Eagerly the step is host bound (~50 scalar parameters, dozens of small launches: ~1 ms at BASELINE C2 against 0.34 ms
 of GPU work); every launch of the C ABI goes to torch's current stream and nothing on the path synchronises or
-allocates outside torch's allocator, so the step captures as it is.  Single process only (a process group's watchdog
-thread may touch the device during capture); tile sizes are fixed at capture time, the point / label buffers of the
-batch are refilled in place between replays.
+allocates outside torch's allocator, so the step captures as it is.  Tile sizes are fixed at capture time, the point /
+label buffers of the batch are refilled in place between replays.
+
+Under a live process group (one rank per GPU, the training config of SURVEY 8e / core.lit_modules' `pl.Trainer(gpus=-1)`)
+the step is TWO graphs with the one real exchange of the path between them:
+    graph 1: zero_grad, voxelise (+GT), forward, criterion, backward      (gradients land at fixed addresses)
+    eager:   ONE all-reduce over the flat vector of the ~50 scalar gradients (RCCL over xGMI on a node)
+    graph 2: optimizer.step()
+Capture uses the relaxed (thread-local) error mode, so the group's watchdog thread may keep calling into HIP.
 """
 from __future__ import annotations
 
@@ -41,18 +47,21 @@ def allreduce_flat_grads(params: Iterable[torch.Tensor], group=None, average: bo
 
 class CapturedTrainingStep:
     """step = zero_grad; grids = pipe.voxelize(batch, want_gt=True); loss = criterion(model(grids.occ), grids.gt_occ,
-    cvx coefficients, GENEO parameters); loss.backward(); optimizer.step().  `replay()` runs it on whatever the
-    batch's device buffers hold and returns the (static) loss tensor."""
+    cvx coefficients, GENEO parameters); loss.backward(); [all-reduce of the gradients over `group`]; optimizer.step().
+    `replay()` runs it on whatever the batch's device buffers hold and returns the (static) loss tensor of THIS rank's
+    tiles.  With a process group of more than one rank every rank must build and replay the step together."""
 
     def __init__(self, pipe: ScenePipeline, criterion: Callable, optimizer: torch.optim.Optimizer, batch: PointBatch,
-                 warmup: int = 3, loss_fn: Optional[Callable] = None):
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
-            raise RuntimeError("CapturedTrainingStep is single-process (capture and a live process group do not mix)")
+                 warmup: int = 3, loss_fn: Optional[Callable] = None, group=None):
+        import torch.distributed as dist
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        self.group = group
         self.pipe, self.criterion, self.optimizer, self.batch = pipe, criterion, optimizer, batch
         model = pipe.model
+        params = [p for p in model.parameters() if p.requires_grad]
 
-        def step():
+        def front():
             optimizer.zero_grad(set_to_none=True)
             grids = pipe.voxelize(batch, want_gt=True)
             pred = model(grids.occ)
@@ -61,10 +70,20 @@ class CapturedTrainingStep:
             else:
                 loss = criterion(pred, grids.gt_occ, model.get_cvx_coefficients(), model.get_geneo_params())
             loss.backward()
+            return loss
+
+        def exchange():
+            if self.world > 1:
+                allreduce_flat_grads(params, group)
+
+        def step():
+            loss = front()
+            exchange()
             optimizer.step()
             return loss
 
         self._eager_step = step
+        self._exchange = exchange
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):   # lazy initialisation, allocator growth, optimiser state -- off the capture
@@ -72,10 +91,23 @@ class CapturedTrainingStep:
                 step()
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)
+        # a live process group's watchdog thread calls into HIP at any time: only this thread's calls are checked
+        mode = "thread_local" if live else "global"
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = step()
+        self.graph_opt = None
+        if self.world == 1:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.loss = step()
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.loss = front()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode=mode):
+                optimizer.step()
 
     def replay(self) -> torch.Tensor:
         self.graph.replay()
+        if self.graph_opt is not None:
+            self._exchange()
+            self.graph_opt.replay()
         return self.loss
