@@ -218,8 +218,13 @@ def test_criteria_have_no_cpu_path():
         crit(torch.rand(2, 1, 4, 4, 4), gt, {}, {})
     with pytest.raises(ValueError):
         sna.WeightedMSE(targets=None, weighting_scheme_path=None)   # the reference builds this error without raising it
-    with pytest.raises(NotImplementedError):
-        sna.BinaryDiceLoss(p=3)
+    # every BinaryDiceLoss power / reduction is served (the fused kernel for p = 2, torch ops on the device otherwise),
+    # none of them on the CPU; an unknown reduction raises at call time like the reference (dice_loss.py:50-51)
+    for crit in (sna.BinaryDiceLoss(p=3), sna.BinaryDiceLoss(reduction="none"), sna.BinaryDiceLoss()):
+        with pytest.raises(sna.HipLibraryError):
+            crit(torch.rand(2, 8), gt.reshape(2, -1)[:, :8])
+    with pytest.raises(Exception, match="Unexpected reduction"):
+        sna.BinaryDiceLoss(reduction="median")(torch.rand(2, 8), torch.rand(2, 8))
 
 
 def test_scene_net_picks_the_linear_forward_only_for_what_it_serves():
