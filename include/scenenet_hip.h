@@ -39,9 +39,12 @@ typedef enum {
     SN_ERR_NO_DEVICE = -4      /* no gfx950 device / HIP runtime unusable            */
 } sn_status;
 
-/* SN_OCC8: uint8 grid whose values are all 0 or 1 (binary occupancy, torch.bool) -- lets sn_conv_bank use the
+/* SN_BF16: bfloat16 STORAGE of activations / their gradients in the training path (reference: `precision: 16`,
+ * experiments/scenenet_ts40k/defaults_config.yml:83-84): accepted as out_dtype of sn_conv_fused, as pred / grad
+ * dtype of sn_loss_forward / sn_loss_backward and as the gradient dtype of sn_conv_corr_t; every sum stays fp32 / fp64.
+ * SN_OCC8: uint8 grid whose values are all 0 or 1 (binary occupancy, torch.bool) -- lets sn_conv_bank use the
  * int8 matrix cores.  SN_U8 is a general 0..255 byte grid. */
-typedef enum { SN_F32 = 0, SN_F64 = 1, SN_U8 = 2, SN_OCC8 = 3 } sn_dtype;
+typedef enum { SN_F32 = 0, SN_F64 = 1, SN_U8 = 2, SN_OCC8 = 3, SN_BF16 = 4 } sn_dtype;
 
 /* GENEO kinds: 0-2 = cylinderv2 / arrow / negSpherev2 of SceneNet (core/models/SCENE_Net.py:259-272);
  * 3-5 = cylinder_kernel / cone_kernel / neg_sphere_kernel of the v1 module SCENE_Net (SCENE_Net.py:158-170). */
@@ -130,7 +133,7 @@ int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lam
  * (equal to 5e-16 in the reference's fp64; core/models/SCENE_Net.py:322-339).  One combined kernel
  * K* = sum_g lambda_g K_g (any G), 24-bit fixed point, Toeplitz-along-y implicit GEMM on v_mfma_i32_16x16x64_i8:
  * 0.375 MFMA per voxel at 9^3 (kernel rows packed at 24 K-bytes for ky <= 9; 0.48 otherwise) instead of 3.  x: SN_OCC8 only ([B,1,Z,X,Y], values in {0,1}, Y % 4 == 0, ky <= 17);
- * out [B,1,Z,X,Y] SN_F32 | SN_F64.  Returns SN_ERR_UNSUPPORTED for other inputs / shapes: call sn_conv_bank then.
+ * out [B,1,Z,X,Y] SN_F32 | SN_F64 | SN_BF16.  Returns SN_ERR_UNSUPPORTED for other inputs / shapes: call sn_conv_bank then.
  * Error vs the 16-kernel contraction: the fixed-point step of K* (<= 2^-23 max|K*| per tap) and fp32 rounding of
  * the combination, ~1e-6 on the output. */
 int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
@@ -287,6 +290,10 @@ int sn_grid_to_points(const void* grid, int dtype, int n0, int n1, int n2, const
 int sn_conv_corr(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X, int Y,
                  int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream);
 int sn_conv_corr_blocks(int B, int Z, int X, int Y);
+/* The same with gout / out of g_dtype SN_F32 or SN_BF16 (bf16 activations: half the bytes of the two grids this pass
+ * reads; the products are formed and summed in fp32 either way). */
+int sn_conv_corr_t(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X, int Y,
+                   int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream);
 
 /* Generator Jacobians: dparams [G, SN_NPARAM] f32 = d<dW, bank(params)>/dparams for dW [G,kz,kx,ky] f32
  * (apex has no gradient: it is truncated to an index, arrow.py:235, and non-trainable, arrow.py:134). */

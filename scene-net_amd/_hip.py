@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SN_HIP_LIB: another build of the same library (A/B timing of kernel variants); default: the in-tree build
 LIB_PATH = os.environ.get("SN_HIP_LIB") or os.path.join(_HERE, "lib", "libscenenet_hip.so")
 
-SN_F32, SN_F64, SN_U8, SN_OCC8 = 0, 1, 2, 3
+SN_F32, SN_F64, SN_U8, SN_OCC8, SN_BF16 = 0, 1, 2, 3, 4
 SN_GENEO_CY, SN_GENEO_CONE, SN_GENEO_NEG = 0, 1, 2
 SN_GENEO_CY_V1, SN_GENEO_CONE_V1, SN_GENEO_NEG_V1 = 3, 4, 5
 SN_P_RADIUS, SN_P_SIGMA, SN_P_APEX, SN_P_CONE_RADIUS, SN_P_CONE_INC, SN_P_NEG_FACTOR = 0, 1, 2, 3, 4, 5
@@ -51,6 +51,7 @@ SYMBOLS = {
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
     "sn_grid_to_points": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "sn_conv_corr_t": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
     "sn_geneo_bank_lambdas": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -184,8 +185,11 @@ def _on_tensor_device(fn):
 
 
 # torch.bool (one byte, 0/1) is the binary-occupancy dtype: sn_conv_bank takes it on the int8 matrix cores
-_DT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_OCC8}
-_DT_OUT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_U8}
+# torch.bfloat16: STORAGE of activations and their gradients in the training path (sn_conv_fused out, sn_loss_* pred /
+# grad, sn_conv_corr_t gradients); never an input grid
+_DT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_OCC8, torch.bfloat16: SN_BF16}
+_DT_OUT = {torch.float32: SN_F32, torch.float64: SN_F64, torch.uint8: SN_U8, torch.bool: SN_U8,
+           torch.bfloat16: SN_BF16}
 
 
 # --------------------------------------------------------------------------- #
@@ -226,7 +230,7 @@ def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tenso
     (act [B,G,Z,X,Y] | None, out [B,1,Z,X,Y] | None) of out_dtype (sn_conv_bank)."""
     if x.dim() != 5 or x.shape[1] != 1:
         raise HipLibraryError(f"x must be [B,1,Z,X,Y] (got {tuple(x.shape)})")
-    if x.dtype not in _DT:
+    if x.dtype not in _DT or x.dtype == torch.bfloat16:
         raise HipLibraryError(f"x dtype {x.dtype} unsupported (f32, f64, u8, bool)")
     B, _, Z, X, Y = x.shape
     G, kz, kx, ky = bank.shape
@@ -525,14 +529,19 @@ def grid_to_points(grid: torch.Tensor, origin=None, voxel_size=None) -> torch.Te
 
 @_on_tensor_device
 def conv_corr(x: torch.Tensor, gout: torch.Tensor, out: Optional[torch.Tensor], kernel_size: Sequence[int]):
-    """C [kz,kx,ky] f32 = sum_{b,v} delta[b,v] x[b, v+t-p]  (sn_conv_corr); gout/out [B,1,Z,X,Y] f32."""
+    """C [kz,kx,ky] f32 = sum_{b,v} delta[b,v] x[b, v+t-p]  (sn_conv_corr_t); gout/out [B,1,Z,X,Y] both f32 or both
+    bf16 (bf16 activation storage: the products are formed and summed in fp32 either way)."""
     B, _, Z, X, Y = x.shape
     kz, kx, ky = (int(k) for k in kernel_size)
+    if gout.dtype not in (torch.float32, torch.bfloat16):
+        raise HipLibraryError(f"gout must be float32 or bfloat16 (got {gout.dtype})")
+    if out is not None and out.dtype != gout.dtype:
+        raise HipLibraryError(f"out ({out.dtype}) and gout ({gout.dtype}) must have the same dtype")
     nblk = load().sn_conv_corr_blocks(B, Z, X, Y)
     ws = torch.empty((nblk, kz * kx * ky), dtype=torch.float32, device=x.device)
     C = torch.empty((kz, kx, ky), dtype=torch.float32, device=x.device)
-    rc = load().sn_conv_corr(_ptr(x, None, "x"), _DT[x.dtype], _ptr(gout, torch.float32, "gout"),
-                             _ptr(out, torch.float32, "out"), B, Z, X, Y, kz, kx, ky, _ptr(ws), _ptr(C), _stream())
+    rc = load().sn_conv_corr_t(_ptr(x, None, "x"), _DT[x.dtype], _ptr(gout, None, "gout"), _ptr(out, None, "out"),
+                               _DT[gout.dtype], B, Z, X, Y, kz, kx, ky, _ptr(ws), _ptr(C), _stream())
     _check(rc, "sn_conv_corr")
     return C
 

@@ -43,7 +43,8 @@ class _DenseLossFn(torch.autograd.Function):
         loss, stats, coef = _hip.loss_forward(pred_c, gt_c, ranges, bin_w, terms, **cfg)
         ctx.save_for_backward(pred_c, gt_c, ranges, coef)
         ctx.mark_non_differentiable(stats)
-        return loss[0].to(pred.dtype), stats
+        # the loss scalar: pred's float dtype; fp32 for bf16 predictions (bf16 is activation storage only)
+        return loss[0].to(pred.dtype if pred.dtype in (torch.float32, torch.float64) else torch.float32), stats
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):

@@ -13,8 +13,8 @@
 namespace sn {  // corr.hip
 int corr_mfma_supported(int kz, int kx, int ky);
 int corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky);
-int corr_mfma_launch(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X, int Y,
-                     int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
+int corr_mfma_launch(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,
+                     int Y, int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
 }  // namespace sn
 
 namespace {
@@ -270,14 +270,22 @@ __global__ __launch_bounds__(256) void geneo_bank_bwd_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X,
-                            int Y, int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream) {
-    if (!x || !gout || !partial_ws || !C) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr: null pointer");
+extern "C" int sn_conv_corr_t(const void* x, int x_dtype, const void* gout_v, const void* out_v, int g_dtype, int B,
+                              int Z, int X, int Y, int kz, int kx, int ky, float* partial_ws, float* C,
+                              sn_stream_t stream) {
+    if (!x || !gout_v || !partial_ws || !C) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr: null pointer");
     if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr: non-positive extent");
+    if (g_dtype != SN_F32 && g_dtype != SN_BF16)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr_t: g_dtype %d (SN_F32 | SN_BF16)", g_dtype);
     // matrix-core kernel (corr.hip) for every kernel extent <= 16; the thread-per-tap kernel below serves the rest
     if (sn::corr_mfma_supported(kz, kx, ky) && sn::corr_mfma_rows(B, Z, X, Y, kz, kx, ky) > 0)
-        return sn::corr_mfma_launch(x, x_dtype, gout, out, B, Z, X, Y, kz, kx, ky, partial_ws, C, sn::as_stream(stream));
+        return sn::corr_mfma_launch(x, x_dtype, gout_v, out_v, g_dtype, B, Z, X, Y, kz, kx, ky, partial_ws, C,
+                                    sn::as_stream(stream));
+    if (g_dtype != SN_F32)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr_t: bf16 gradients need a kernel extent <= 16 per axis");
+    const float* gout = (const float*)gout_v;
+    const float* out = (const float*)out_v;
     const int nzt = (Z + TZ - 1) / TZ, nxt = (X + TX - 1) / TX, nyt = (Y + TY - 1) / TY;
     const size_t lds = ((size_t)(TZ + kz - 1) * (TX + kx - 1) * (TY + ky - 1) + (size_t)TZ * TX * TY) * sizeof(float);
     if (lds > 150 * 1024) return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr: kernel %dx%dx%d too large", kz, kx, ky);
@@ -301,6 +309,11 @@ extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const
 #undef SN_CORR
     hipLaunchKernelGGL(corr_reduce_kernel, dim3((ntaps + 255) / 256), dim3(256), 0, s, partial_ws, nblk, ntaps, C);
     return sn::check_launch("sn_conv_corr");
+}
+
+extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X,
+                            int Y, int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream) {
+    return sn_conv_corr_t(x, x_dtype, gout, out, SN_F32, B, Z, X, Y, kz, kx, ky, partial_ws, C, stream);
 }
 
 extern "C" int sn_conv_corr_blocks(int B, int Z, int X, int Y) {

@@ -333,7 +333,12 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     float rr[4] = {0.f, 0.f, 0.f, 0.f};
     auto store4 = [&](OT* o, int gy, const float (&r)[4]) {
         if (gy + 3 < s.Y) {
-            if constexpr (sizeof(OT) == 4) {
+            if constexpr (sizeof(OT) == 2) {   // bf16 storage: four values, one 8-byte store
+                const OT h[4] = {(OT)r[0], (OT)r[1], (OT)r[2], (OT)r[3]};
+                uint2 u;
+                __builtin_memcpy(&u, h, 8);
+                *reinterpret_cast<uint2*>(o) = u;
+            } else if constexpr (sizeof(OT) == 4) {
                 *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
             } else {
                 reinterpret_cast<double2*>(o)[0] = make_double2((double)r[0], (double)r[1]);
@@ -564,7 +569,7 @@ extern "C" int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int k
 // returns SN_ERR_UNSUPPORTED (without touching the error text) when the shape is outside this kernel
 int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
                        int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream) {
-    if (((uintptr_t)x % 4) || ((uintptr_t)out % 16)) return SN_ERR_UNSUPPORTED;
+    if (((uintptr_t)x % 4) || ((uintptr_t)out % (out_dtype == SN_BF16 ? 8 : 16))) return SN_ERR_UNSUPPORTED;
     LinShape s;
     size_t lds = 0;
     bool w24 = false;
@@ -574,6 +579,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     if (grid > s.ntiles) grid = s.ntiles;
     s.dbg = getenv("SN_CONV_LIN_DBG") ? atoi(getenv("SN_CONV_LIN_DBG")) : 0;
     s.tol = sn::option_conv_i8_tolerance();
+    if (out_dtype == SN_BF16) s.tol = 0.0f;   // bf16 storage rounds at 2^-9: the 24-bit fixed point is not what limits it
     s.route = nullptr;
     if (s.tol > 0.0f) {
         s.route = sn::device_flag_slot();
@@ -588,6 +594,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     } while (0)
     if (out_dtype == SN_F32) SN_LAUNCH_LIN(float);
     else if (out_dtype == SN_F64) SN_LAUNCH_LIN(double);
+    else if (out_dtype == SN_BF16) SN_LAUNCH_LIN(__bf16);
     else return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: out_dtype %d", out_dtype);
 #undef SN_LAUNCH_LIN
     if (int rc = sn::check_launch("sn_conv_fused")) return rc;

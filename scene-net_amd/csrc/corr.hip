@@ -23,8 +23,8 @@
 namespace sn {
 int corr_mfma_supported(int kz, int kx, int ky);
 int corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky);
-int corr_mfma_launch(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X, int Y,
-                     int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
+int corr_mfma_launch(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,
+                     int Y, int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
 }  // namespace sn
 
 namespace {
@@ -55,14 +55,19 @@ __device__ __forceinline__ void load_quad(const float* p, float (&v)[4]) {
     const float4 f = *reinterpret_cast<const float4*>(p);
     v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
 }
+__device__ __forceinline__ void load_quad(const __bf16* p, float (&v)[4]) {   // bf16 storage: 8 bytes, widened to fp32
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
 __device__ __forceinline__ void load_quad(const double* p, float (&v)[4]) {
     const double2 a = reinterpret_cast<const double2*>(p)[0], b = reinterpret_cast<const double2*>(p)[1];
     v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b.x; v[3] = (float)b.y;
 }
 
-template <typename XT, int KZMAX>
-__global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel(const XT* __restrict__ x, const float* __restrict__ gout,
-                                                             const float* __restrict__ out, CorrShape s,
+template <typename XT, int KZMAX, typename DT>
+__global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel(const XT* __restrict__ x, const DT* __restrict__ gout,
+                                                             const DT* __restrict__ out, CorrShape s,
                                                              float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dl = lds;                                 // [DR][DS]   delta rows q0 .. q0+DR-1
@@ -144,9 +149,9 @@ __global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel
                 float d = 0.f;
                 if (c < s.Y && q >= 0 && q < s.X) {
                     const size_t idx = dbase + (size_t)q * s.Y + c;
-                    d = gout[idx];
+                    d = (float)gout[idx];
                     if (out) {
-                        const float o = out[idx];
+                        const float o = (float)out[idx];
                         d = (o > 0.f) ? d * (1.f - o * o) : 0.f;
                     }
                 }
@@ -319,22 +324,32 @@ int sn::corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky) {
     return plan(B, Z, X, Y, kz, kx, ky, &s, &lds, &grid) ? grid : 0;
 }
 
-int sn::corr_mfma_launch(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X, int Y,
-                         int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t stream) {
+int sn::corr_mfma_launch(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,
+                         int Y, int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t stream) {
     CorrShape s;
     size_t lds;
     int grid;
     if (!plan(B, Z, X, Y, kz, kx, ky, &s, &lds, &grid))
         return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr: shape outside the MFMA correlation kernel");
     const size_t xa = (x_dtype == SN_U8 || x_dtype == SN_OCC8) ? 4 : 16;
-    s.vec = (Y % 4 == 0) && ((uintptr_t)x % xa == 0) && ((uintptr_t)gout % 16 == 0) &&
-            (!out || (uintptr_t)out % 16 == 0);
+    const size_t ga = g_dtype == SN_BF16 ? 8 : 16;
+    s.vec = (Y % 4 == 0) && ((uintptr_t)x % xa == 0) && ((uintptr_t)gout % ga == 0) &&
+            (!out || (uintptr_t)out % ga == 0);
 #define SN_CORR_LAUNCH(XT, KZMAX)                                                                                 \
     do {                                                                                                          \
-        auto kern = corr_mfma_kernel<XT, KZMAX>;                                                                  \
-        if (sn::ensure_dynamic_lds((const void*)kern, (int)lds) != hipSuccess)                                    \
-            return sn::check_launch("sn_conv_corr(hipFuncSetAttribute)");                                         \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, (const XT*)x, gout, out, s, partial_ws); \
+        if (g_dtype == SN_BF16) {                                                                                 \
+            auto kern = corr_mfma_kernel<XT, KZMAX, __bf16>;                                                      \
+            if (sn::ensure_dynamic_lds((const void*)kern, (int)lds) != hipSuccess)                                \
+                return sn::check_launch("sn_conv_corr(hipFuncSetAttribute)");                                     \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, (const XT*)x, (const __bf16*)gout,  \
+                               (const __bf16*)out, s, partial_ws);                                                \
+        } else {                                                                                                  \
+            auto kern = corr_mfma_kernel<XT, KZMAX, float>;                                                       \
+            if (sn::ensure_dynamic_lds((const void*)kern, (int)lds) != hipSuccess)                                \
+                return sn::check_launch("sn_conv_corr(hipFuncSetAttribute)");                                     \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, (const XT*)x, (const float*)gout,   \
+                               (const float*)out, s, partial_ws);                                                 \
+        }                                                                                                         \
     } while (0)
 #define SN_CORR_KZ(XT)                                                                                            \
     do {                                                                                                          \

@@ -16,6 +16,10 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxBins = SN_LOSS_MAX_BINS;
 
+using bf16 = __bf16;   // SN_BF16: storage only -- every value is widened to fp32 before it is used
+template <typename T> struct ComputeOf { using type = T; };
+template <> struct ComputeOf<bf16> { using type = float; };
+
 template <typename T>
 struct Vec4 {
     T v[4];
@@ -24,7 +28,10 @@ struct Vec4 {
 template <typename T>
 __device__ __forceinline__ Vec4<T> load4(const T* p) {
     Vec4<T> r;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 2) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        __builtin_memcpy(&r, &u, 8);
+    } else if constexpr (sizeof(T) == 4) {
         const uint4 u = *reinterpret_cast<const uint4*>(p);
         __builtin_memcpy(&r, &u, 16);
     } else if constexpr (sizeof(T) == 8) {
@@ -40,7 +47,11 @@ __device__ __forceinline__ Vec4<T> load4(const T* p) {
 
 template <typename T>
 __device__ __forceinline__ void store4(T* p, const Vec4<T>& r) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 2) {
+        uint2 u;
+        __builtin_memcpy(&u, &r, 8);
+        *reinterpret_cast<uint2*>(p) = u;
+    } else if constexpr (sizeof(T) == 4) {
         uint4 u;
         __builtin_memcpy(&u, &r, 16);
         *reinterpret_cast<uint4*>(p) = u;
@@ -112,7 +123,8 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
     __shared__ double red[kThreads / 64][3 * kMaxBins + 5];
     __shared__ double sq_l[kBinary ? 1 : kMaxBins * kThreads];
     __shared__ int cnt_l[kBinary ? 1 : kMaxBins * kThreads];
-    using BT = PT;  // per-thread per-bin BCE partials in pred's precision (a few hundred terms each)
+    using CT = typename ComputeOf<PT>::type;   // arithmetic type of pred-precision terms (bf16 storage: fp32)
+    using BT = CT;  // per-thread per-bin BCE partials in pred's precision (a few hundred terms each)
     __shared__ BT bce_l[kBinary ? 1 : kMaxBins * kThreads];
     const bool want_bce = (terms & SN_LOSS_WBCE) != 0;
     __shared__ int lut[256];
@@ -130,7 +142,8 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
     if constexpr (kBinary) {
         double sq_all = 0, sq1 = 0, bce_all = 0, bce1 = 0;
         int n_all = 0, n1 = 0;
-        auto take = [&](PT pv, GT tv) {
+        auto take = [&](PT pv_, GT tv) {
+            const CT pv = (CT)pv_;
             const double pd = (double)pv;
             const bool one = tv != 0;
             const double e = (one ? 1.0 : 0.0) - pd, e2 = e * e;
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
             s_p += pd;
             s_pp += pd * pd;
             if (want_bce) {  // torch BCELoss: -(t max(log p, -100) + (1 - t) max(log(1 - p), -100)), in pred's dtype
-                const PT l = bce_log<PT>(one ? pv : (PT)1 - pv);
+                const CT l = bce_log<CT>(one ? pv : (CT)1 - pv);
                 bce_all -= (double)l;
                 bce1 -= one ? (double)l : 0.0;
             }
@@ -174,15 +187,16 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
         if constexpr (sizeof(GT) == 1) lut[tid] = bin((GT)tid);
         for (int k = 0; k < H; ++k) sq_l[k * kThreads + tid] = 0.0, cnt_l[k * kThreads + tid] = 0, bce_l[k * kThreads + tid] = (BT)0;
         __syncthreads();
-        auto take = [&](PT pv, GT tv) {
+        auto take = [&](PT pv_, GT tv) {
+            const CT pv = (CT)pv_;
             const double pd = (double)pv, td = (double)tv;
             const double e = td - pd;
             const int k = bin_lookup(bin, lut, tv) * kThreads + tid;
             sq_l[k] += e * e;
             cnt_l[k] += 1;
             if (want_bce) {
-                const PT tt = (PT)tv;
-                bce_l[k] -= tt * bce_log<PT>(pv) + ((PT)1 - tt) * bce_log<PT>((PT)1 - pv);
+                const CT tt = (CT)tv;
+                bce_l[k] -= tt * bce_log<CT>(pv) + ((CT)1 - tt) * bce_log<CT>((CT)1 - pv);
             }
             s_pt += pd * td;
             s_p += pd;
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
                                                              int H, const double* __restrict__ coef,
                                                              const double* __restrict__ upstream,
                                                              PT* __restrict__ grad) {
-    using C = PT;  // gradient arithmetic in pred's dtype
+    using C = typename ComputeOf<PT>::type;  // gradient arithmetic in pred's dtype (bf16 storage: fp32)
     __shared__ C ck[kMaxBins], ek[kMaxBins];
     __shared__ int lut[256];
     const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -470,13 +484,15 @@ int check_common(const char* fn, const void* pred, int pred_dtype, const void* g
     if (!pred || !gt || !ranges) return sn::fail(SN_ERR_INVALID_ARG, "%s: null pointer", fn);
     if (B <= 0 || n_per <= 0) return sn::fail(SN_ERR_INVALID_ARG, "%s: B and n_per must be positive", fn);
     if (H < 1 || H > kMaxBins) return sn::fail(SN_ERR_UNSUPPORTED, "%s: 1 <= H <= %d bins", fn, kMaxBins);
-    if (pred_dtype != SN_F32 && pred_dtype != SN_F64)
-        return sn::fail(SN_ERR_INVALID_ARG, "%s: pred must be SN_F32 or SN_F64", fn);
+    if (pred_dtype != SN_F32 && pred_dtype != SN_F64 && pred_dtype != SN_BF16)
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: pred must be SN_F32, SN_F64 or SN_BF16", fn);
+    if (pred_dtype == SN_BF16 && gt_dtype == SN_F64)
+        return sn::fail(SN_ERR_UNSUPPORTED, "%s: bf16 predictions take SN_F32 / SN_U8 / SN_OCC8 targets", fn);
     if (gt_dtype != SN_F32 && gt_dtype != SN_F64 && gt_dtype != SN_U8 && gt_dtype != SN_OCC8)
         return sn::fail(SN_ERR_INVALID_ARG, "%s: bad gt dtype %d", fn, gt_dtype);
-    const size_t pa = 16, ga = (gt_dtype == SN_F64 || gt_dtype == SN_F32) ? 16 : 4;
+    const size_t pa = pred_dtype == SN_BF16 ? 8 : 16, ga = (gt_dtype == SN_F64 || gt_dtype == SN_F32) ? 16 : 4;
     if (n_per % 4 == 0 && (((uintptr_t)pred % pa) || ((uintptr_t)gt % ga)))
-        return sn::fail(SN_ERR_INVALID_ARG, "%s: pred / gt must be 16-byte (byte gt: 4-byte) aligned", fn);
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: pred / gt must be 16-byte (bf16 pred: 8-byte, byte gt: 4-byte) aligned", fn);
     return SN_OK;
 }
 
@@ -490,7 +506,11 @@ long span_of(int64_t n_per, int nparts) {
 
 #define SN_LOSS_DISPATCH(KERNEL)                                                                                  \
     do {                                                                                                          \
-        if (pred_dtype == SN_F32) {                                                                               \
+        if (pred_dtype == SN_BF16) {                                                                              \
+            if (gt_dtype == SN_F32) KERNEL(bf16, float, false);                                                   \
+            else if (gt_dtype == SN_OCC8) KERNEL(bf16, uint8_t, true);                                            \
+            else KERNEL(bf16, uint8_t, false);                                                                    \
+        } else if (pred_dtype == SN_F32) {                                                                        \
             if (gt_dtype == SN_F32) KERNEL(float, float, false);                                                  \
             else if (gt_dtype == SN_F64) KERNEL(float, double, false);                                            \
             else if (gt_dtype == SN_OCC8) KERNEL(float, uint8_t, true);                                           \
@@ -544,8 +564,8 @@ extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt
                                 void* grad_pred, sn_stream_t stream) {
     if (int rc = check_common("sn_loss_backward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
     if (!coef || !grad_pred) return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: null pointer");
-    if (n_per % 4 == 0 && ((uintptr_t)grad_pred % 16))
-        return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: grad_pred must be 16-byte aligned");
+    if (n_per % 4 == 0 && ((uintptr_t)grad_pred % (pred_dtype == SN_BF16 ? 8 : 16)))
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: grad_pred must be 16-byte (bf16: 8-byte) aligned");
     if (B > 65535) return sn::fail(SN_ERR_UNSUPPORTED, "sn_loss_backward: B <= 65535");
     hipStream_t s = sn::as_stream(stream);
     // the gradient pass has no reduction tail: 8192-element spans ([measured] 13.8 us; 14.6 us at the statistics

@@ -115,6 +115,11 @@ class SceneNet(nn.Module):
     # combined kernel sum_i lambda_i K_i, ~4x faster, same output to ~5e-6); set False to force the 16-kernel
     # contraction (sn_conv_bank) everywhere.
     fused_forward = True
+    # Storage dtype of the forward output where the linear forward (sn_conv_fused) serves the shape: None = the input's
+    # float dtype (f32 for byte grids); torch.bfloat16 = bf16 activations for training (the reference's `precision:
+    # 16`, defaults_config.yml:83-84): the prediction, its gradient from the criterion and what the backward
+    # correlation reads are then 2 bytes per voxel; every sum stays fp32 / fp64.
+    activation_dtype = None
     # lambda init range as a function of the number of GENEOs (SCENE_Net.py:276-277)
     LAMBDA_RANGE = staticmethod(lambda n: (-2 / n, 1 / n))
 
@@ -309,7 +314,7 @@ class SceneNet(nn.Module):
             live.packed, live.leaves = weakref.ref(P), tuple(params)
             live.mask_params, live.mask_cvx, live.mask_all = meta["mask_params"], meta["mask_cvx"], meta["mask_all"]
             out, act = _GeneoForwardFn.apply(x.contiguous(), P, flat, meta, ks, return_bank_activations,
-                                             bool(self.fused_forward))
+                                             bool(self.fused_forward), self.activation_dtype)
             live.versions = tuple(p._version for p in params)
             self._lambda_cache = None  # lambdas_dict[last_lambda] was refreshed in place (SCENE_Net.py:333)
             return (out, act) if return_bank_activations else out
@@ -319,7 +324,7 @@ class SceneNet(nn.Module):
             out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
             if self.fused_forward and not return_bank_activations:
                 if _hip.conv_fused_supported(x, ks):
-                    return _hip.conv_fused(x.contiguous(), bank, lam, out_dtype=out_dtype)
+                    return _hip.conv_fused(x.contiguous(), bank, lam, out_dtype=self.activation_dtype or out_dtype)
                 if x.dtype in (torch.float32, torch.float64):
                     # what the reference feeds is f64 {0., 1.} (ToFullDense): a device-side check routes such grids
                     # to the int8 kernels and anything else to the fp32 contraction, without a host sync
@@ -335,13 +340,15 @@ class _GeneoForwardFn(torch.autograd.Function):
     coefficient sn_effective_lambdas refreshes in place."""
 
     @staticmethod
-    def forward(ctx, x, P, flat, meta, kernel_size, want_act, fused=False):
+    def forward(ctx, x, P, flat, meta, kernel_size, want_act, fused=False, act_dtype=None):
         G = meta["G"]
         n = G * _hip.SN_NPARAM
         p = flat[:n].view(G, _hip.SN_NPARAM)
         bank, lam = _hip.geneo_bank_lambdas(p, meta["kinds"], kernel_size, flat[n:], meta["order"], meta["last"])
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
         if fused and not want_act and _hip.conv_fused_supported(x, kernel_size):
+            if act_dtype is not None:   # bf16 activation storage (SceneNet.activation_dtype): the linear forward writes it
+                out_dtype = act_dtype
             act, out = None, _hip.conv_fused(x, bank, lam, out_dtype=out_dtype)   # forward through linearity
         elif fused and not want_act and x.dtype in (torch.float32, torch.float64):
             act, out = None, _hip.forward_auto(x, bank, lam)[0]                    # float grid, usually {0., 1.}
@@ -359,13 +366,14 @@ class _GeneoForwardFn(torch.autograd.Function):
         x, out, bank, P, lam, kinds = ctx.saved_tensors
         G = ctx.G
         n = G * _hip.SN_NPARAM
-        C = _hip.conv_corr(x, gout.to(torch.float32).contiguous(), out.to(torch.float32).contiguous(),
-                           ctx.kernel_size)                      # [kz,kx,ky]
+        # bf16 activations stay bf16 (half the bytes of the two grids this pass reads; products and sums are fp32)
+        gdt = torch.bfloat16 if out.dtype == torch.bfloat16 else torch.float32
+        C = _hip.conv_corr(x, gout.to(gdt).contiguous(), out.to(gdt).contiguous(), ctx.kernel_size)   # [kz,kx,ky]
         # dL/dK_g = lambda_g C and dL/dlambda_g = <K_g, C> (minus the frozen coefficient's, SCENE_Net.py:331), the
         # generator Jacobians and the packing into gP: one launch
         gP = torch.empty_like(P)
         _hip.geneo_backward(P[:n].view(G, _hip.SN_NPARAM), kinds, ctx.kernel_size, bank, lam, C, ctx.last, gP)
-        return None, gP, None, None, None, None, None
+        return None, gP, None, None, None, None, None, None
 
 
 class SCENE_Net(SceneNet):
