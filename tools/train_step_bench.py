@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--graph", action="store_true", help="also capture the whole step in a hipGraph and replay it")
+    ap.add_argument("--bf16", action="store_true", help="bf16 activation storage (SceneNet.activation_dtype; BASELINE C5)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     geneo_num = {"cy": 6, "cone": 5, "neg": 5}
@@ -50,6 +51,8 @@ def main():
     model = sna.SceneNet(geneo_num, (9, 9, 9))
     apply_bank_spec(model, specs, names, lambdas, last)
     model = model.to(dev)
+    if args.bf16:
+        model.activation_dtype = torch.bfloat16
     tiles, labels = zip(*[synthetic_tile(i, args.points) for i in range(args.batch)])
     batch = sna.PointBatch.from_tiles(tiles, labels, device=dev)
     pipe = sna.ScenePipeline(model, (args.grid,) * 3, keep_labels=[15.0])
@@ -88,6 +91,7 @@ def main():
 
     t_step = timed(step, args.iters)
     t_inf = timed(fwd_only, args.iters)
+    print(f"activations   {str(pred.dtype)}")
     print(f"training step {t_step:8.3f} ms  -> {args.batch / t_step * 1e3:9.0f} tiles/s   "
           f"(inference through the module: {t_inf:.3f} ms)")
 
