@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--voxel-size", type=float, nargs=3, default=None, metavar=("SX", "SY", "SZ"),
+                    help="voxel-size mode (semKITTI.py:453-455): per-scan grid extents computed on the device, grids "
+                         "padded to --grid^3 (e.g. 0.8 0.8 0.8 for ~100 m scans at 128^3)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     specs, names, lambdas, last = synthetic_bank_spec({"cy": 6, "cone": 5, "neg": 5})
@@ -54,7 +57,12 @@ def main():
 
     def step():
         with torch.no_grad():
-            pred, grids = pipe(batch, want_gt=True)
+            if args.voxel_size is None:
+                pred, grids = pipe(batch, want_gt=True)
+            else:   # size mode: bbox -> per-scan descriptor on the device -> counting scatter -> padded binary grids
+                grids = sna.voxelize_batch(batch, (args.grid,) * 3, [80.0], want_occ=True, want_gt_occ=True,
+                                           voxel_dims=args.voxel_size, occ_dtype=torch.bool)
+                pred = model(grids.occ)
             return sna.point_predictions(pred, batch, grids, tau=0.5), grids
 
     import gc
@@ -77,7 +85,8 @@ def main():
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / args.iters
     npts = batch.total_points
-    print(f"C4-like: {args.batch} scans x {npts // args.batch} points, {args.grid}^3: {ms:.3f} ms/batch = "
+    mode = "n-mode grid" if args.voxel_size is None else f"voxel size {tuple(args.voxel_size)}, dims {grids.dims[0].tolist()}.."
+    print(f"C4-like ({mode}): {args.batch} scans x {npts // args.batch} points, {args.grid}^3: {ms:.3f} ms/batch = "
           f"{args.batch / ms * 1e3:.0f} scans/s = {npts / ms * 1e3 / 1e6:.0f} Mpoints/s; occupancy "
           f"{grids.occ.float().mean().item():.4f}; points flagged {per_point.mean().item():.4f}")
 
