@@ -506,20 +506,32 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             constexpr std::integral_constant<int, 1> I1{};
             // raw dwords of a tail step for x-row h, [j][b]: a quad slot holds D2 of its four kernel rows; an odd-row chunk
             // slot holds D_c, D_c+1 in b = 0, 1
-            auto tail_load = [&](auto TS, auto H, uint32_t (&raw)[4][4]) {
+            // the byte offsets of a tail step's quad rows (the same for both x-rows): one batch of LDS reads, requested a
+            // phase before the raw dwords that need them ([measured] read inside tail_load -- table read, wait, four raw
+            // reads, four times over -- a tail load was eight dependent LDS round trips: 30 us of a lone wave's 157)
+            auto tail_offsets = [&](auto TS, int4 (&to)[4]) {
+                constexpr int ts = decltype(TS)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * ts + j;
+                    if (t < NT) to[j] = toff[t * 4 + q];
+                    else if (ODD && t - NT < 2) to[j] = make_int4(oddoff[q] + 4 * (t - NT), 0, 0, 0);
+                    else to[j] = make_int4(0, 0, 0, 0);
+                }
+            };
+            auto tail_load = [&](auto TS, auto H, const int4 (&to)[4], uint32_t (&raw)[4][4]) {
                 constexpr int ts = decltype(TS)::value, h = decltype(H)::value;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int t = 4 * ts + j;
                     if (t < NT) {
-                        const int4 to = toff[t * 4 + q];
                         const uint8_t* p = xb + h * (DW * 4) + 8;
-                        raw[j][0] = *reinterpret_cast<const uint32_t*>(p + to.x);
-                        raw[j][1] = *reinterpret_cast<const uint32_t*>(p + to.y);
-                        raw[j][2] = *reinterpret_cast<const uint32_t*>(p + to.z);
-                        raw[j][3] = *reinterpret_cast<const uint32_t*>(p + to.w);
+                        raw[j][0] = *reinterpret_cast<const uint32_t*>(p + to[j].x);
+                        raw[j][1] = *reinterpret_cast<const uint32_t*>(p + to[j].y);
+                        raw[j][2] = *reinterpret_cast<const uint32_t*>(p + to[j].z);
+                        raw[j][3] = *reinterpret_cast<const uint32_t*>(p + to[j].w);
                     } else if (ODD && t - NT < 2) {
-                        const uint32_t* p = reinterpret_cast<const uint32_t*>(xb + h * (DW * 4) + oddoff[q] + 4 * (t - NT));
+                        const uint32_t* p = reinterpret_cast<const uint32_t*>(xb + h * (DW * 4) + to[j].x);
                         raw[j][0] = p[0];
                         raw[j][1] = p[1];
                         raw[j][2] = 0u;
@@ -596,20 +608,23 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                 pair_compute(wb, db);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            int4 to[4];   // row offsets of the current tail step
             if (NP - np_loop == 2) {
                 load_w(np_loop + 1, wb);
                 load_raw(rb, db);
+                tail_offsets(I0, to);
                 __builtin_amdgcn_sched_barrier(0);
                 pair_compute(wa, da);
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(NP, wa);   // the first tail step's digits
-                tail_load(I0, I0, ta);
+                tail_load(I0, I0, to, ta);
                 __builtin_amdgcn_sched_barrier(0);
                 pair_compute(wb, db);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 load_w(NP, wb);
-                tail_load(I0, I0, ta);
+                tail_offsets(I0, to);
+                tail_load(I0, I0, to, ta);
                 __builtin_amdgcn_sched_barrier(0);
                 pair_compute(wa, da);
                 __builtin_amdgcn_sched_barrier(0);
@@ -621,16 +636,17 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             // ---- tail steps (at most two; the first one's digits are in wa, its x-row 0 raw dwords in ta): the raw dwords
             // of the next (step, x-row) are requested before the 12 MFMAs of the current one
             if (NTS > 1) load_w(NP + 1, wb);
-            tail_load(I0, I1, tb);
+            tail_load(I0, I1, to, tb);
+            if (NTS > 1) tail_offsets(I1, to);   // (after the reads that use the first step's)
             __builtin_amdgcn_sched_barrier(0);
             tail_compute(I0, I0, ta, wa);
             __builtin_amdgcn_sched_barrier(0);
-            if (NTS > 1) tail_load(I1, I0, ta);
+            if (NTS > 1) tail_load(I1, I0, to, ta);
             __builtin_amdgcn_sched_barrier(0);
             tail_compute(I0, I1, tb, wa);
             __builtin_amdgcn_sched_barrier(0);
             if (NTS > 1) {
-                tail_load(I1, I1, tb);
+                tail_load(I1, I1, to, tb);
                 __builtin_amdgcn_sched_barrier(0);
                 tail_compute(I1, I0, ta, wb);
                 __builtin_amdgcn_sched_barrier(0);
