@@ -249,7 +249,8 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     int* done = landed + 4;                                                      // [kNB]  waves finished with the buffer
     int* flags = done + 4;                                                       // [4]    0: route, 1: a spin gave up
     int* rclaim = flags + 4;                                                     // [kNB]  round tickets drawn per ring slot
-    uint32_t* hbuf = reinterpret_cast<uint32_t*>(rclaim + 4);                    // [kNB][hdw] raw halo dwords
+    short* plan_s = reinterpret_cast<short*>(rclaim + 4);                        // [2][4][kMaxRQ] the row plan (halo, tap): indexed per lane
+    uint32_t* hbuf = reinterpret_cast<uint32_t*>(plan_s + 2 * 4 * kMaxRQ);       // [kNB][hdw] raw halo dwords
     float* bank_s = reinterpret_cast<float*>(hbuf + (size_t)2 * hdw);            // [G][ntaps] (+1 pad), prologue only: over ring slot 2
                                                                                  // (first filled during tile 0's rounds) and beyond
 
@@ -258,6 +259,11 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 #endif
     const int my_tiles = (int)blockIdx.x < s.ntiles ? (s.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     if (tid < 16) landed[tid] = 0;   // landed[0..3], done[0..3], flags[0..3], rclaim[0..3]
+    // the row plan is indexed per lane below: from the kernel argument that is a vector load from memory per use
+    // ([measured] tables 4.8 us); one coalesced copy into LDS rides with the bank's loads
+    if (tid < 2 * 4 * kMaxRQ) plan_s[tid] = reinterpret_cast<const short*>(&s.plan)[tid];
+    const short* plan_halo = plan_s;                  // [4][kMaxRQ]
+    const short* plan_tap = plan_s + 4 * kMaxRQ;      // [4][kMaxRQ]
     {   // fp32 bank -> LDS, coalesced, one batch of loads; the first two tiles' halos are requested while those loads fly
         // (the other way round the bank's loads queue behind 24 DMA pieces per wave: vmcnt retires in order) and
         // travel while the tables are built
@@ -285,15 +291,17 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     lds_barrier();
     SN_ST(1);
     // ---- per kernel: max|W|, the fixed-point scale, and the exact worst case of the quantisation error
-    for (int g = wave; g < 16; g += kWaves) {
+    {   // all 16 kernels at once: half a wave each (two passes of whole waves took 4.7 us: two dependent reduction chains)
+        static_assert(2 * kWaves == 16, "one half wave per kernel");
+        const int g = 2 * wave + (lane >> 5), l32 = lane & 31;
         float m = 0.0f;
         if (g < s.G)
-            for (int t = lane; t < ntaps; t += 64) {
+            for (int t = l32; t < ntaps; t += 32) {
                 const float a = fabsf(bank_s[g * ntaps + t]);
                 m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);   // NaN / inf poisons the kernel
             }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 16; o > 0; o >>= 1) {
             const float u = __shfl_xor(m, o, 64);
             m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
         }
@@ -301,18 +309,18 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
         const double invS = (double)m / kQMax;   // Q * invS instead of Q / S: 2e-16 relative, nothing next to the errors summed
         double ep = 0.0, en = 0.0;
         if (g < s.G && m > 0.0f)
-            for (int t = lane; t < ntaps; t += 64) {
+            for (int t = l32; t < ntaps; t += 32) {
                 const double w = (double)bank_s[g * ntaps + t];
                 const double e = (double)__double2int_rn(w * S) * invS - w;
                 ep += e > 0.0 ? e : 0.0;
                 en += e < 0.0 ? -e : 0.0;
             }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 16; o > 0; o >>= 1) {
             ep += __shfl_xor(ep, o, 64);
             en += __shfl_xor(en, o, 64);
         }
-        if (lane == 0) {
+        if (l32 == 0) {
             Sq[g] = S;
             scale[g] = (m != m) ? m : (float)((double)m / kQMax);
             bnd[g] = ep > en ? ep : en;
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (st < s.NP) {
-                    const int krow = s.plan.tap[qq][2 * st + (j >> 1)];
+                    const int krow = plan_tap[qq * kMaxRQ + 2 * st + (j >> 1)];
 #pragma unroll
                     for (int b = 0; b < 4; ++b) put(j, b, krow, 4 * (j & 1) + b);
                 } else {
@@ -368,10 +376,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const int ri = 4 * t + b;
-                            put(j, b, ri < s.RQ ? s.plan.tap[qq][ri] : -1, 8);
+                            put(j, b, ri < s.RQ ? plan_tap[qq * kMaxRQ + ri] : -1, 8);
                         }
                     } else if (s.ODD && t - s.NT < 2) {
-                        const int krow = s.plan.tap[qq][s.RQ - 1];
+                        const int krow = plan_tap[qq * kMaxRQ + s.RQ - 1];
 #pragma unroll
                         for (int b = 0; b < 4; ++b) put(j, b, krow, 4 * (t - s.NT) + b);
                     }
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     }
     for (int i = tid; i < s.NP * 4; i += kThreads) {
         const int qq = i & 3, st = i >> 2;
-        roff[i] = make_int2(s.plan.halo[qq][2 * st] * (DW * 4), s.plan.halo[qq][2 * st + 1] * (DW * 4));
+        roff[i] = make_int2(plan_halo[qq * kMaxRQ + 2 * st] * (DW * 4), plan_halo[qq * kMaxRQ + 2 * st + 1] * (DW * 4));
     }
     for (int i = tid; i < s.NT * 4; i += kThreads) {
         const int qq = i & 3, t = i >> 2;
@@ -392,11 +400,11 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int ri = 4 * t + b;
-            o[b] = s.plan.halo[qq][ri < s.RQ ? ri : s.RQ - 1] * (DW * 4);
+            o[b] = plan_halo[qq * kMaxRQ + (ri < s.RQ ? ri : s.RQ - 1)] * (DW * 4);
         }
         toff[i] = make_int4(o[0], o[1], o[2], o[3]);
     }
-    if (tid < 4) oddoff[tid] = s.plan.halo[tid][s.RQ - 1] * (DW * 4);
+    if (tid < 4) oddoff[tid] = plan_halo[tid * kMaxRQ + s.RQ - 1] * (DW * 4);
     SN_ST(3);
 
     // lambda_g * scale_g next to the scales: the epilogue reads its four of each per round (16-byte LDS reads) instead
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 
 size_t lds_bytes(const Shape& s) {
     const size_t hdw = (size_t)s.ZP * s.XP * DW;
-    return (size_t)s.KS * 3 * 64 * 16 + (size_t)s.NP * 4 * 8 + (size_t)s.NT * 4 * 16 + 16 + 64 + 64 + 128 + 128 + 64 +
+    return (size_t)s.KS * 3 * 64 * 16 + (size_t)s.NP * 4 * 8 + (size_t)s.NT * 4 * 16 + 16 + 64 + 64 + 128 + 128 + 64 + sizeof(RowPlan) +
            (kNB * hdw * 4 > 2 * hdw * 4 + ((size_t)s.G * s.kz * s.kx * 9 + 1) * sizeof(float)
                 ? kNB * hdw * 4 : 2 * hdw * 4 + ((size_t)s.G * s.kz * s.kx * 9 + 1) * sizeof(float)) + 16;
 }
