@@ -311,10 +311,14 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
         if (g < s.G && m > 0.0f)
             for (int t = l32; t < ntaps; t += 32) {
                 const double w = (double)bank_s[g * ntaps + t];
-                const double e = (double)__double2int_rn(w * S) * invS - w;
+                const int Q = __double2int_rn(w * S);
+                const double e = (double)Q * invS - w;
                 ep += e > 0.0 ? e : 0.0;
                 en += e < 0.0 ? -e : 0.0;
+                bank_s[g * ntaps + t] = __int_as_float(Q);   // the table build below reads the fixed-point weight, not W
             }
+        else if (g < s.G)
+            for (int t = l32; t < ntaps; t += 32) bank_s[g * ntaps + t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {
             ep += __shfl_xor(ep, o, 64);
@@ -352,10 +356,9 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
         const int g = l & 15, qq = l >> 4;
         uint32_t w0[4] = {0u, 0u, 0u, 0u}, w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
         if (g < s.G) {
-            const double S = Sq[g];
-            auto put = [&](int j, int b, int krow, int dy) {
-                if (krow < 0) return;
-                int Q = __double2int_rn((double)bank_s[g * ntaps + krow * 9 + dy] * S);
+            auto put = [&](int j, int b, int krow, int dy) {   // branch-free (krow < 0: Q = 0) so that the 16 reads of an entry go out together
+                int Q = __float_as_int(bank_s[g * ntaps + (krow < 0 ? 0 : krow) * 9 + dy]);
+                Q = krow < 0 ? 0 : Q;
                 const int d0 = ((Q + 128) & 255) - 128;
                 Q = (Q - d0) >> 8;
                 const int d1 = ((Q + 128) & 255) - 128;
