@@ -498,19 +498,38 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                 for (int d = 0; d < 3; ++d)
                     acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv, first ? i32x4{0, 0, 0, 0} : acc[d][v], 0, 0, 0);
             };
+            // One pair step: 24 MFMAs and the 24 v_alignbyte that shift the raw dwords for residues 1..3.  Issue order is
+            // fixed by hand -- four v_alignbyte (an operand used two groups later), then three MFMAs, ... -- so that the
+            // VALU work always sits behind a running MFMA and never in front of one that needs it: left to the scheduler it
+            // came out in clumps of eight, which idle the matrix pipe for half their length whenever the SIMD's other wave
+            // is not in its own steps ([measured] a lone wave drove the pipe at 63 % inside these steps).
             auto pair_compute = [&](const i32x4 (&w)[3], const uint32_t (&d)[2][2][3], bool first = false) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t a0 = d[h][0][0], a1 = d[h][0][1], a2 = d[h][0][2];
-                    const uint32_t b0 = d[h][1][0], b1 = d[h][1][1], b2 = d[h][1][2];
-                    mma_tile(w, i32x4{(int)a0, (int)a1, (int)b0, (int)b1}, 4 * h + 0, first);
-                    mma_tile(w, i32x4{(int)window<1>(a1, a0), (int)window<1>(a2, a1), (int)window<1>(b1, b0),
-                                      (int)window<1>(b2, b1)}, 4 * h + 1, first);
-                    mma_tile(w, i32x4{(int)window<2>(a1, a0), (int)window<2>(a2, a1), (int)window<2>(b1, b0),
-                                      (int)window<2>(b2, b1)}, 4 * h + 2, first);
-                    mma_tile(w, i32x4{(int)window<3>(a1, a0), (int)window<3>(a2, a1), (int)window<3>(b1, b0),
-                                      (int)window<3>(b2, b1)}, 4 * h + 3, first);
-                }
+                auto shifted = [&](int h, auto R) -> i32x4 {
+                    constexpr int r = decltype(R)::value;
+                    return i32x4{(int)window<r>(d[h][0][1], d[h][0][0]), (int)window<r>(d[h][0][2], d[h][0][1]),
+                                 (int)window<r>(d[h][1][1], d[h][1][0]), (int)window<r>(d[h][1][2], d[h][1][1])};
+                };
+                constexpr std::integral_constant<int, 1> R1{};
+                constexpr std::integral_constant<int, 2> R2{};
+                constexpr std::integral_constant<int, 3> R3{};
+                const i32x4 x00{(int)d[0][0][0], (int)d[0][0][1], (int)d[0][1][0], (int)d[0][1][1]};
+                const i32x4 x10{(int)d[1][0][0], (int)d[1][0][1], (int)d[1][1][0], (int)d[1][1][1]};
+#define SN_FENCE() __builtin_amdgcn_sched_barrier(0)
+                const i32x4 x01 = shifted(0, R1); SN_FENCE();
+                mma_tile(w, x00, 0, first);       SN_FENCE();
+                const i32x4 x02 = shifted(0, R2); SN_FENCE();
+                mma_tile(w, x10, 4, first);       SN_FENCE();
+                const i32x4 x03 = shifted(0, R3); SN_FENCE();
+                mma_tile(w, x01, 1, first);       SN_FENCE();
+                const i32x4 x11 = shifted(1, R1); SN_FENCE();
+                mma_tile(w, x02, 2, first);       SN_FENCE();
+                const i32x4 x12 = shifted(1, R2); SN_FENCE();
+                mma_tile(w, x03, 3, first);       SN_FENCE();
+                const i32x4 x13 = shifted(1, R3); SN_FENCE();
+                mma_tile(w, x11, 5, first);
+                mma_tile(w, x12, 6, first);
+                mma_tile(w, x13, 7, first);
+#undef SN_FENCE
             };
 
             constexpr std::integral_constant<int, 0> I0{};
@@ -845,7 +864,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     const char* dbg = getenv("SN_CONV_I8_DBG");
     s.dbg = dbg ? atoi(dbg) : 0;
     const char* stg = getenv("SN_CONV_I8S_STAGGER");
-    s.stagger = stg ? atoi(stg) : 100;   // x 64 clocks: about half a round
+    s.stagger = stg ? atoi(stg) : 0;   // x 64 clocks; [measured] 100 (about half a round) vs 0: 0.2045 vs 0.2039 ms -- rounds are claimed, the waves spread by themselves
     const char* stat = getenv("SN_CONV_I8S_STATIC");
     s.dynamic = !(stat && stat[0] == '1');
     const int cus = num_cus();
