@@ -503,7 +503,8 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             // VALU work always sits behind a running MFMA and never in front of one that needs it: left to the scheduler it
             // came out in clumps of eight, which idle the matrix pipe for half their length whenever the SIMD's other wave
             // is not in its own steps ([measured] a lone wave drove the pipe at 63 % inside these steps).
-            auto pair_compute = [&](const i32x4 (&w)[3], const uint32_t (&d)[2][2][3], bool first = false) {
+            auto no_extra = [](int) {};
+            auto pair_compute = [&](const i32x4 (&w)[3], const uint32_t (&d)[2][2][3], bool first, auto&& extra) {
                 auto shifted = [&](int h, auto R) -> i32x4 {
                     constexpr int r = decltype(R)::value;
                     return i32x4{(int)window<r>(d[h][0][1], d[h][0][0]), (int)window<r>(d[h][0][2], d[h][0][1]),
@@ -526,9 +527,12 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                 const i32x4 x12 = shifted(1, R2); SN_FENCE();
                 mma_tile(w, x03, 3, first);       SN_FENCE();
                 const i32x4 x13 = shifted(1, R3); SN_FENCE();
-                mma_tile(w, x11, 5, first);
-                mma_tile(w, x12, 6, first);
-                mma_tile(w, x13, 7, first);
+                mma_tile(w, x11, 5, first);       SN_FENCE();
+                extra(0);                         SN_FENCE();   // (the last pair step: the first tail transposes ride here)
+                mma_tile(w, x12, 6, first);       SN_FENCE();
+                extra(1);                         SN_FENCE();
+                mma_tile(w, x13, 7, first);       SN_FENCE();
+                extra(2);
 #undef SN_FENCE
             };
 
@@ -572,28 +576,35 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                     }
                 }
             };
-            auto tail_compute = [&](auto TS, auto H, const uint32_t (&raw)[4][4], const i32x4 (&w)[3]) {
-                constexpr int ts = decltype(TS)::value, h = decltype(H)::value;
-                uint32_t xr[4][4];   // [residue][j]
+            // slot j of tail step TS for one x-row: raw dwords -> the K dword of every residue, x[r][j]
+            auto tail_slot = [&](auto TS, int j, const uint32_t (&raw)[4][4], uint32_t (&x)[4][4]) {
+                constexpr int ts = decltype(TS)::value;
+                const int t = 4 * ts + j;
+                if (t < NT) {
+                    uint32_t o[4];
+                    transpose4(raw[j][0], raw[j][1], raw[j][2], raw[j][3], o);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int t = 4 * ts + j;
-                    if (t < NT) {
-                        uint32_t o[4];
-                        transpose4(raw[j][0], raw[j][1], raw[j][2], raw[j][3], o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) xr[r][j] = o[r];
-                    } else {   // odd-row chunk (or an unused slot: all zero)
-                        const uint32_t lo = raw[j][0], hi = raw[j][1];
-                        xr[0][j] = lo;
-                        xr[1][j] = window<1>(hi, lo);
-                        xr[2][j] = window<2>(hi, lo);
-                        xr[3][j] = window<3>(hi, lo);
-                    }
+                    for (int r = 0; r < 4; ++r) x[r][j] = o[r];
+                } else {   // odd-row chunk (or an unused slot: all zero)
+                    const uint32_t lo = raw[j][0], hi = raw[j][1];
+                    x[0][j] = lo;
+                    x[1][j] = window<1>(hi, lo);
+                    x[2][j] = window<2>(hi, lo);
+                    x[3][j] = window<3>(hi, lo);
                 }
+            };
+            // the 12 MFMAs of one (tail step, x-row); work(r) is issued behind residue r's three -- the next (step, x-row)'s
+            // transposes, eight v_perm at a time ([measured] with all 32 in front of their own MFMAs a lone wave spent
+            // 0.8 us per round in the tail steps for 0.3 us of matrix work)
+            auto tail_mma = [&](auto H, const uint32_t (&x)[4][4], const i32x4 (&w)[3], auto&& work) {
+                constexpr int h = decltype(H)::value;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    mma_tile(w, i32x4{(int)xr[r][0], (int)xr[r][1], (int)xr[r][2], (int)xr[r][3]}, 4 * h + r);
+                for (int r = 0; r < 4; ++r) {
+                    mma_tile(w, i32x4{(int)x[r][0], (int)x[r][1], (int)x[r][2], (int)x[r][3]}, 4 * h + r);
+                    __builtin_amdgcn_sched_barrier(0);
+                    work(r);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             };
 
             // ---- pair steps, two register sets: step st+1's operands are requested before step st's 24 MFMAs issue; the
@@ -614,13 +625,13 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                 load_raw(rb, db);
                 ra = roff[2 * 4 + q];
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wa, da, true);
+                pair_compute(wa, da, true, no_extra);
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(2, wa);
                 load_raw(ra, da);
                 rb = roff[(3 < NP ? 3 : NP - 1) * 4 + q];
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wb, db);
+                pair_compute(wb, db, false, no_extra);
                 __builtin_amdgcn_sched_barrier(0);
             }
             int st = 2;
@@ -629,58 +640,70 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                 load_raw(rb, db);
                 ra = roff[(st + 2) * 4 + q];
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wa, da);
+                pair_compute(wa, da, false, no_extra);
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(st + 2, wa);
                 load_raw(ra, da);
                 rb = roff[(st + 3 < NP ? st + 3 : NP - 1) * 4 + q];
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wb, db);
+                pair_compute(wb, db, false, no_extra);
                 __builtin_amdgcn_sched_barrier(0);
             }
             int4 to[4];   // row offsets of the current tail step
+            uint32_t xa[4][4], xq[4][4];   // a (tail step, x-row)'s K dwords [residue][slot], ping-pong
+            // the first tail (step, x-row)'s transposes ride behind the last MFMAs of the last pair step
+            auto first_transposes = [&](int k) {
+                if (k == 0) tail_slot(I0, 0, ta, xa);
+                if (k == 1) tail_slot(I0, 1, ta, xa);
+                if (k == 2) { tail_slot(I0, 2, ta, xa); tail_slot(I0, 3, ta, xa); }
+            };
             if (NP - np_loop == 2) {
                 load_w(np_loop + 1, wb);
                 load_raw(rb, db);
                 tail_offsets(I0, to);
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wa, da);
+                pair_compute(wa, da, false, no_extra);
                 __builtin_amdgcn_sched_barrier(0);
                 load_w(NP, wa);   // the first tail step's digits
                 tail_load(I0, I0, to, ta);
+                tail_load(I0, I1, to, tb);
+                if (NTS > 1) tail_offsets(I1, to);   // (behind the reads that use the first step's)
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wb, db);
+                pair_compute(wb, db, false, first_transposes);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 load_w(NP, wb);
                 tail_offsets(I0, to);
                 tail_load(I0, I0, to, ta);
+                tail_load(I0, I1, to, tb);
+                if (NTS > 1) tail_offsets(I1, to);
                 __builtin_amdgcn_sched_barrier(0);
-                pair_compute(wa, da);
+                pair_compute(wa, da, false, first_transposes);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d = 0; d < 3; ++d) wa[d] = wb[d];
             }
             SN_WT(1, t_r1);
             const unsigned long long t_r2 = SN_WNOW();
-            // ---- tail steps (at most two; the first one's digits are in wa, its x-row 0 raw dwords in ta): the raw dwords
-            // of the next (step, x-row) are requested before the 12 MFMAs of the current one
-            if (NTS > 1) load_w(NP + 1, wb);
-            tail_load(I0, I1, to, tb);
-            if (NTS > 1) tail_offsets(I1, to);   // (after the reads that use the first step's)
+            // ---- tail steps (at most two; the first one's digits are in wa): every (step, x-row)'s 12 MFMAs carry the
+            // next one's transposes, whose raw dwords were requested a phase earlier
+            if (NTS > 1) {
+                load_w(NP + 1, wb);
+                tail_load(I1, I0, to, ta);   // ta's dwords are in xa
+            }
             __builtin_amdgcn_sched_barrier(0);
-            tail_compute(I0, I0, ta, wa);
-            __builtin_amdgcn_sched_barrier(0);
-            if (NTS > 1) tail_load(I1, I0, to, ta);
-            __builtin_amdgcn_sched_barrier(0);
-            tail_compute(I0, I1, tb, wa);
+            tail_mma(I0, xa, wa, [&](int r) { tail_slot(I0, r, tb, xq); });
             __builtin_amdgcn_sched_barrier(0);
             if (NTS > 1) {
-                tail_load(I1, I1, to, tb);
+                tail_load(I1, I1, to, tb);   // tb's dwords are in xq
                 __builtin_amdgcn_sched_barrier(0);
-                tail_compute(I1, I0, ta, wb);
+                tail_mma(I1, xq, wa, [&](int r) { tail_slot(I1, r, ta, xa); });
                 __builtin_amdgcn_sched_barrier(0);
-                tail_compute(I1, I1, tb, wb);
+                tail_mma(I0, xa, wb, [&](int r) { tail_slot(I1, r, tb, xq); });
+                __builtin_amdgcn_sched_barrier(0);
+                tail_mma(I1, xq, wb, no_extra);
+            } else {
+                tail_mma(I1, xq, wa, no_extra);
             }
             SN_WT(2, t_r2);
             const unsigned long long t_r3 = SN_WNOW();
