@@ -573,15 +573,15 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 continue;
             }
             // S = S2*65536 + (S1*256 + S0): the low pair fits int32 (|.| < 2^25), one fp32 rounding each
-            float val[NV][4];
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int low = acc[1][v][r] * 256 + acc[0][v][r];
-                    val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);  // unscaled: x 2^-F_g below
-                }
             if (act) {
+                float val[NV][4];
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int low = acc[1][v][r] * 256 + acc[0][v][r];
+                        val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);  // unscaled: x 2^-F_g below
+                    }
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int gx = c.x0 + lx + (v >> 2), gy = c.y0 + (v & 3) * 16 + n;
@@ -600,10 +600,15 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
                 float sums[NV];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    float p = lam[0] * val[v][0];
-                    p = fmaf(lam[1], val[v][1], p);
-                    p = fmaf(lam[2], val[v][2], p);
-                    p = fmaf(lam[3], val[v][3], p);
+                    // sum_r lam_r (low_r + 65536 hi_r), two FMAs per kernel straight from the integer sums: the same
+                    // operations in the same order as conv_i8s.hip's epilogue (bit-identical heads), with or without `act`
+                    float p = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int low = acc[1][v][r] * 256 + acc[0][v][r];
+                        p = fmaf(lam[r], (float)low, p);
+                        p = fmaf(65536.0f * lam[r], (float)acc[2][v][r], p);
+                    }
                     p += __shfl_xor(p, 32, 64);   // (q, q+2) then (q, q+1): the association conv_i8s.hip's swaps give
                     p += __shfl_xor(p, 16, 64);
                     sums[v] = p;

@@ -184,6 +184,10 @@ __device__ __forceinline__ bool wave_wait(const int* c, int expect) {
 
 // 4x4 byte transpose: o[r] = (a.byte r, b.byte r, c.byte r, d.byte r)
 __device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t (&o)[4]) {
+#ifdef SN_I8S_NOALIGN
+    o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+    return;
+#endif
     const uint32_t p0 = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a0 b0 a1 b1
     const uint32_t p1 = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a2 b2 a3 b3
     const uint32_t q0 = __builtin_amdgcn_perm(d, c, 0x05010400u);   // c0 d0 c1 d1
@@ -197,7 +201,11 @@ __device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, u
 template <int R>
 __device__ __forceinline__ uint32_t window(uint32_t hi, uint32_t lo) {   // bytes R .. R+3 of (hi : lo)
     if constexpr (R == 0) return lo;
+#ifdef SN_I8S_NOALIGN   // timing experiment (wrong results): how much of the launch is the v_alignbyte / v_perm issue slots
+    else return lo;
+#else
     else return __builtin_amdgcn_alignbyte(hi, lo, R);
+#endif
 }
 
 #ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING OUT=build/timing OBJDIR=build/obj_timing; read by tools/i8s_timing.py
@@ -243,8 +251,8 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     int* oddoff = reinterpret_cast<int*>(toff + s.NT * 4);                       // [4]       byte offset of the odd row
     float* scale = reinterpret_cast<float*>(oddoff + 4);                         // [16]   max|W_g| / 8355711
     float* lamsc = scale + 16;                                                   // [16]   lambda_g * scale_g
-    double* Sq = reinterpret_cast<double*>(lamsc + 16);                          // [16]   8355711 / max|W_g|
-    double* bnd = Sq + 16;                                                       // [16]   worst-case error per kernel
+    float* lamhi = lamsc + 16;                                                   // [16]   65536 * lambda_g * scale_g (+ 64 bytes spare)
+    double* bnd = reinterpret_cast<double*>(lamhi + 32);                                                       // [16]   worst-case error per kernel
     int* landed = reinterpret_cast<int*>(bnd + 16);                              // [kNB]  waves whose DMA pieces are in
     int* done = landed + 4;                                                      // [kNB]  waves finished with the buffer
     int* flags = done + 4;                                                       // [4]    0: route, 1: a spin gave up
@@ -325,7 +333,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             en += __shfl_xor(en, o, 64);
         }
         if (l32 == 0) {
-            Sq[g] = S;
             scale[g] = (m != m) ? m : (float)((double)m / kQMax);
             bnd[g] = ep > en ? ep : en;
         }
@@ -412,7 +419,11 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 
     // lambda_g * scale_g next to the scales: the epilogue reads its four of each per round (16-byte LDS reads) instead
     // of holding eight registers through the MFMA loop
-    if (tid < 16) lamsc[tid] = (out && tid < s.G) ? lambdas[tid] * scale[tid] : 0.0f;
+    if (tid < 16) {
+        const float ls = (out && tid < s.G) ? lambdas[tid] * scale[tid] : 0.0f;
+        lamsc[tid] = ls;
+        lamhi[tid] = 65536.0f * ls;   // exact
+    }
     if (my_tiles == 0 || (s.dbg & 8)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -717,51 +728,70 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                     for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(acc[d][v]));
                 continue;
             }
-            float val[NV][4];
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int low = acc[1][v][r] * 256 + acc[0][v][r];   // |.| < 2^25: exact
-                    val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);
-                }
             const int gy4 = c.y0 + 4 * n;   // this lane's four residues: y = gy4 .. gy4 + 3
-            const float4 sc4 = *reinterpret_cast<const float4*>(scale + 4 * q);
-            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-            if (act && gy4 < s.Y) {
+            float pm[NV];                   // this lane group's share of the head's mix, per tile
+            const float4 lam4 = *reinterpret_cast<const float4*>(lamsc + 4 * q);
+            const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
+            if (act) {
+                // bank activations requested: every (kernel, voxel) value is formed, stored, and mixed
+                float val[NV][4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int gx = c.x0 + lx + h;
-                    if (gx < s.X) {
+                for (int v = 0; v < NV; ++v)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int g = 4 * q + r;
-                            if (g < s.G) {
-                                OT* o = act + ((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy4;
-                                const float v0 = val[4 * h + 0][r] * sc[r], v1 = val[4 * h + 1][r] * sc[r],
-                                            v2 = val[4 * h + 2][r] * sc[r], v3 = val[4 * h + 3][r] * sc[r];
-                                if constexpr (sizeof(OT) == 4) {
-                                    *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
-                                } else {
-                                    reinterpret_cast<double2*>(o)[0] = make_double2((double)v0, (double)v1);
-                                    reinterpret_cast<double2*>(o)[1] = make_double2((double)v2, (double)v3);
+                    for (int r = 0; r < 4; ++r) {
+                        const int low = acc[1][v][r] * 256 + acc[0][v][r];   // |.| < 2^25: exact
+                        val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);
+                    }
+                const float4 sc4 = *reinterpret_cast<const float4*>(scale + 4 * q);
+                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+                if (gy4 < s.Y) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int gx = c.x0 + lx + h;
+                        if (gx < s.X) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int g = 4 * q + r;
+                                if (g < s.G) {
+                                    OT* o = act + ((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy4;
+                                    const float v0 = val[4 * h + 0][r] * sc[r], v1 = val[4 * h + 1][r] * sc[r],
+                                                v2 = val[4 * h + 2][r] * sc[r], v3 = val[4 * h + 3][r] * sc[r];
+                                    if constexpr (sizeof(OT) == 4) {
+                                        *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
+                                    } else {
+                                        reinterpret_cast<double2*>(o)[0] = make_double2((double)v0, (double)v1);
+                                        reinterpret_cast<double2*>(o)[1] = make_double2((double)v2, (double)v3);
+                                    }
                                 }
                             }
                         }
                     }
                 }
             }
-            if (out) {
-                const float4 lam4 = *reinterpret_cast<const float4*>(lamsc + 4 * q);
-                const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
-                float pm[NV];
+            {
+                // the head's mix: sum_r lam_r (low_r + 65536 hi_r) as two packed FMAs per kernel and PAIR of tiles, straight
+                // from the integer accumulators (the same bits with or without `act`) -- 128 VALU per round instead of 164 (a VALU instruction costs the SIMD about
+                // 2.5 cycles next to a busy matrix pipe: tools/micro/mfma_valu_mix.hip)
+                using f32x2 = __attribute__((ext_vector_type(2))) float;
+                const float4 hi4 = *reinterpret_cast<const float4*>(lamhi + 4 * q);
+                const float lhi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    float p = lam[0] * val[v][0];
-                    p = fmaf(lam[1], val[v][1], p);
-                    p = fmaf(lam[2], val[v][2], p);
-                    pm[v] = fmaf(lam[3], val[v][3], p);
+                for (int vp = 0; vp < NV / 2; ++vp) {
+                    const int v0 = 2 * vp, v1 = 2 * vp + 1;
+                    f32x2 p = {0.0f, 0.0f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int low0 = acc[1][v0][r] * 256 + acc[0][v0][r], low1 = acc[1][v1][r] * 256 + acc[0][v1][r];
+                        const f32x2 lo = {(float)low0, (float)low1};
+                        const f32x2 hi = {(float)acc[2][v0][r], (float)acc[2][v1][r]};
+                        p = __builtin_elementwise_fma(f32x2{lam[r], lam[r]}, lo, p);
+                        p = __builtin_elementwise_fma(f32x2{lhi[r], lhi[r]}, hi, p);
+                    }
+                    pm[v0] = p.x;
+                    pm[v1] = p.y;
                 }
+            }
+            if (out) {
                 // sum over the four lane groups (the 16 kernels) with half / row swaps: one v_permlane32_swap + add sums
                 // TWO tiles over lanes (l, l + 32) -- tile a ends in the lower half, b in the upper --, one
                 // v_permlane16_swap + add does the same inside the halves.  Lane group q ends up holding exactly what it
