@@ -435,6 +435,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
         for (int i = 0; i < s.stagger; i += 100) __builtin_amdgcn_s_sleep(100);
 
     const int half_tx = s.TX >> 1;
+    const int hx_shift = 31 - __builtin_clz(half_tx);
     const int nrounds = s.TZ * half_tx;
     const size_t V = (size_t)s.Z * s.X * s.Y;
     bool healthy = true;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             SN_WT(4, t_r0);
             const unsigned long long t_r1 = SN_WNOW();
             if ((s.dbg & 128) && wave >= kWaves / 2) continue;   // timing experiment: one wave per SIMD works
-            const int lz = round / half_tx, lx = (round - lz * half_tx) * 2;
+            const int lz = round >> hx_shift, lx = (round & (half_tx - 1)) * 2;   // TX / 2 is a power of two (cand[] below)
             const uint8_t* xb = hb + ((lz * s.XP + lx) * DW + n + D0) * 4;
 
             i32x4 acc[3][NV];   // not zeroed: the first step's MFMAs take the constant 0 as their C operand
@@ -924,7 +925,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
     bool found = false;
     for (const auto& c : cand) {
-        s.TZ = c[0]; s.TX = c[1];
+        s.TZ = c[0]; s.TX = c[1];   // (TX / 2 a power of two: the kernel splits a round index by shift and mask)
         s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
         const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
         if (nt > 0x7fffffff) return 1;
