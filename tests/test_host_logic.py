@@ -237,13 +237,19 @@ def test_scene_net_picks_the_linear_forward_only_for_what_it_serves():
     assert sna.SceneNet.fused_forward is True
 
 
-def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01_final_bench.json (stdout of bench.py on the MI355X box) carries every key the driver's contract names,
-    the roofline and CPU-baseline objects, and internally consistent figures."""
+@pytest.mark.parametrize("name", ["r01_final_bench.json", "r02_bench.json"])
+def test_committed_bench_line_keeps_the_contract(name):
+    """profiles/<name> (stdout of bench.py on the MI355X box) carries every key the driver's contract names, the roofline
+    and CPU-baseline objects, and internally consistent figures (round 2 adds the fp32 and cold figures and the ranks)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01_final_bench.json")))
+    d = json.load(open(os.path.join(root, "profiles", name)))
+    if name.startswith("r02"):
+        for k in ("value_fp32", "ms_per_step_fp32", "value_cold", "ms_per_step_cold", "rccl_ranks", "per_rank_tiles_per_s"):
+            assert k in d, k
+        assert d["rccl_ranks"] == d["n_gpus"] == len(d["per_rank_tiles_per_s"])
+        assert d["value_fp32"] < d["value_cold"] <= 1.02 * d["value"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
