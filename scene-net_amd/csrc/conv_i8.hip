@@ -34,9 +34,10 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 // relu(tanh(v)): 0 for v <= 0, else 1 - 2 / (exp(2v) + 1) on the hardware exp / rcp (abs. error ~2e-7, inside the 1e-4
 // bar; same form as conv_lin.hip and conv_i8s.hip).  NaN stays NaN like torch.relu(torch.tanh(.)); +inf -> 1.
 __device__ __forceinline__ float relu_tanh(float v) {
-    if (v != v) return v;
-    if (!(v > 0.0f)) return 0.0f;
-    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
+    // branch-free, v_exp_f32 + v_rcp_f32 (1 ulp; the correctly rounded reciprocal was ten instructions, twice per lane and round)
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f);
+    const float r = (v > 0.0f) ? t : 0.0f;
+    return (v != v) ? v : r;
 }
 
 constexpr int kThreads = 512;

@@ -38,9 +38,10 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 // relu(tanh(v)): 0 for v <= 0, else 1 - 2 / (exp(2v) + 1) on the hardware exp / rcp (abs. error ~2e-7, inside the 1e-4
 // bar; same form as conv_lin.hip).  NaN stays NaN like torch.relu(torch.tanh(.)); +inf -> 1.
 __device__ __forceinline__ float relu_tanh(float v) {
-    if (v != v) return v;
-    if (!(v > 0.0f)) return 0.0f;
-    return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
+    // branch-free, v_exp_f32 + v_rcp_f32 (1 ulp; the correctly rounded reciprocal was ten instructions, twice per lane and round)
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f);
+    const float r = (v > 0.0f) ? t : 0.0f;
+    return (v != v) ? v : r;
 }
 
 constexpr int kThreads = 512;
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     if (!s.gate.pass()) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, q = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: what derives from it (a round's rows,
+    const int n = lane & 15, q = lane >> 4;                                        // addresses) is then scalar arithmetic, not VALU
     SN_ST(0);
 
     const int NP = kNT >= 0 ? kNP : s.NP;
@@ -810,7 +811,9 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                 const int h = q >> 1;
                 const int gx = c.x0 + lx + h, gy = gy4 + 2 * (q & 1);
                 if (gx < s.X && gy < s.Y) {
-                    OT* o = out + (size_t)c.b * V + ((size_t)gz * s.X + gx) * s.Y + gy;
+                    // wave-uniform row base (scalar arithmetic) + a 32-bit lane offset: no 64-bit vector address math per round
+                    OT* row = out + ((size_t)c.b * V + ((size_t)gz * s.X + (c.x0 + lx)) * s.Y + c.y0);
+                    OT* o = row + (unsigned)(h * s.Y + 4 * n + 2 * (q & 1));
                     float t0 = e0, t1 = e1;
                     if (s.head & 1) { t0 += (float)load_now(o); t1 += (float)load_now(o + 1); }
                     if (s.head & 2) { t0 = relu_tanh(t0); t1 = relu_tanh(t1); }
