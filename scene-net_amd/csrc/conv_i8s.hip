@@ -17,8 +17,14 @@
 //     2 1/4 K-dwords, not 3:  81 rows -> 183 dwords -> 12 MFMA steps of 16 dwords instead of 16 (-25 % MFMAs);
 //   * the 65 KiB the shifted copies took hold a RING of three halo buffers filled by LDS-DMA two tiles ahead.
 //     A wave moves from tile to tile on two LDS counters per buffer (landed / done) -- no workgroup barrier in the
-//     tile loop -- so the two waves of a SIMD can run half a round apart for the whole launch: one wave's epilogue
-//     and DMA issue overlap its partner's MFMAs (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+//     tile loop --, and rounds are claimed from an LDS ticket counter, so the two waves of a SIMD drift apart by
+//     themselves and one's epilogue meets the other's MFMAs (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+//
+// Cost model ([measured], tools/micro/mfma_valu_mix.hip and DESIGN.md section 4): a launch takes about 19.5 cycles per
+// MFMA plus 2.5 cycles per VALU instruction, summed over both waves of a SIMD -- VALU work is NOT hidden behind the
+// partner's MFMAs.  Hence the instruction-count discipline below: operand shifts issued four at a time behind running
+// MFMAs, tail offsets read in batches, the head mixed straight from the integer sums with packed FMAs, the wave index
+// kept scalar, the head's tanh on v_exp / v_rcp.
 //
 // Quantisation (per kernel g): S_g = 8355711 / max|W_g| (8355711 = 127 * 65793, the largest magnitude three
 // balanced digits hold), Q = rint(W * S_g) in fp64, act = S * (max|W_g| / 8355711).  The prologue also computes the
