@@ -65,6 +65,10 @@ enum {
 };
 
 int sn_version(void);
+/* Diagnostics: how many sn_conv_bank launches (this device, this process) the folded int8 kernel served [0], declined
+ * because the bank was not symmetric in x and y [1], and handed to the fp32 kernel because the quantisation bound
+ * exceeded the tolerance [2].  Synchronises the device.  (No reference counterpart.) */
+int sn_conv_i8_path_counts(unsigned long long* counts3);
 const char* sn_last_error(void);
 
 /* Number of gfx950 devices visible (0 when none); never throws. */
@@ -78,6 +82,9 @@ int sn_device_count(void);
  *       binary occupancy) quantise the weights to 24-bit fixed point and compute, on the device, the exact worst case
  *       of the resulting activation error over all binary inputs.  A bank whose bound exceeds value * 1e-9 is computed
  *       by the fp32 kernel instead (decided on the device, no host synchronisation).  0 switches the guard off.
+ *   "conv_i8_fold" (default 1): 9 x 9 x 9 banks that are bit-for-bit symmetric in x and y (every GENEO bank) are
+ *       contracted over 9 x 5 x 5 folded taps (exactly the same integer sums, a third of the MFMAs); the symmetry is
+ *       checked on the device at every call, other banks take the unfolded kernel; 0 = never try
  *   "conv_i8_legacy" (default 0): 1 = sn_conv_bank uses the four-copy int8 kernel (conv_i8.hip) for every shape
  *       instead of the stride-4 kernel (conv_i8s.hip) it prefers for ky = 9 (A/B timing, parity tests of both). */
 int sn_set_option(const char* name, int value);

@@ -9,7 +9,7 @@ import ctypes
 import functools
 import os
 from ctypes import c_char_p, c_int, c_void_p
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -29,6 +29,7 @@ SYMBOLS = {
     "sn_version": (c_int, []),
     "sn_last_error": (c_char_p, []),
     "sn_device_count": (c_int, []),
+    "sn_conv_i8_path_counts": (c_int, [_P]),
     "sn_set_option": (c_int, [c_char_p, _I]),
     "sn_get_option": (c_int, [c_char_p]),
     "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -106,6 +107,14 @@ def set_option(name: str, value: int) -> None:
 
 def get_option(name: str) -> int:
     return int(load().sn_get_option(name.encode()))
+
+
+def conv_i8_path_counts() -> Tuple[int, int, int]:
+    """(served by the folded int8 kernel, declined by it: bank not symmetric, sent to the fp32 kernel by its guard) --
+    launches of this process on the current device; synchronises (sn_conv_i8_path_counts)."""
+    buf = (ctypes.c_ulonglong * 3)()
+    _check(load().sn_conv_i8_path_counts(ctypes.cast(buf, ctypes.c_void_p)), "sn_conv_i8_path_counts")
+    return int(buf[0]), int(buf[1]), int(buf[2])
 
 
 def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str = "tensor") -> Optional[int]:

@@ -16,6 +16,8 @@ static std::atomic<int> g_skip_empty{0};
 int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8_legacy{0};
 int option_conv_i8_legacy() { return g_i8_legacy.load(std::memory_order_relaxed); }
+static std::atomic<int> g_i8_fold{1};
+int option_conv_i8_fold() { return g_i8_fold.load(std::memory_order_relaxed); }
 
 static thread_local Gate g_gate{{nullptr, nullptr, nullptr}, {0, 0, 0}};
 Gate current_gate() { return g_gate; }
@@ -85,6 +87,10 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_i8_legacy.store(value ? 1 : 0, std::memory_order_relaxed);
         return SN_OK;
     }
+    if (strcmp(name, "conv_i8_fold") == 0) {
+        sn::g_i8_fold.store(value ? 1 : 0, std::memory_order_relaxed);
+        return SN_OK;
+    }
     return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: unknown option '%s'", name);
 }
 
@@ -92,6 +98,7 @@ extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_skip_empty_tiles") == 0) return sn::option_conv_skip_empty_tiles();
     if (name && strcmp(name, "conv_i8_tolerance_ppb") == 0) return sn::g_i8_tol_ppb.load(std::memory_order_relaxed);
     if (name && strcmp(name, "conv_i8_legacy") == 0) return sn::option_conv_i8_legacy();
+    if (name && strcmp(name, "conv_i8_fold") == 0) return sn::option_conv_i8_fold();
     return -1;
 }
 

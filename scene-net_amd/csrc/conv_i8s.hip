@@ -71,6 +71,18 @@ struct RowPlan {
     short tap[4][kMaxRQ];    // kernel row index dz * kx + dx, -1 = pad (zero weights)
 };
 
+// The folded kernel (conv_occ_i8f_kernel): kernel rows (dz, dx') of a bank that is symmetric in x and y, dx' = 0..4.
+// kFoldSteps MFMA steps of kFoldRows folded rows per lane group; slot (st, j) is SINGLE (dx' = 4: one halo row) for j = 2 of
+// steps 0..2 and DOUBLE (dx' < 4: halo rows dx' and 8 - dx' summed) elsewhere -- the same for all four lane groups, so the
+// step code has no per-lane case.
+constexpr int kFoldSteps = 4, kFoldRows = 3, kFoldSlots = kFoldSteps * kFoldRows;
+constexpr bool fold_slot_single(int st, int j) { return j == 2 && st < 3; }
+struct FoldPlan {
+    short h1[4][kFoldSlots];    // halo row index dz * XP + dx'
+    short h2[4][kFoldSlots];    // halo row index dz * XP + 8 - dx'   (single slots: unused)
+    short tap[4][kFoldSlots];   // kernel row dz * 9 + dx', -1 = pad (zero weights)
+};
+
 struct Shape {
     int B, Z, X, Y, G;
     int kz, kx;
@@ -86,6 +98,7 @@ struct Shape {
     int dynamic;           // rounds of a tile are claimed from an LDS ticket counter (else dealt: wave, wave + 8, ...)
     int dbg;
     RowPlan plan;
+    FoldPlan fplan;        // conv_occ_i8f_kernel only
 };
 
 struct TileCoord {
@@ -102,6 +115,8 @@ __device__ __forceinline__ TileCoord tile_coord(const Shape& s, int tile) {
 }
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_word_s[4] = {0u, 0u, 0u, 0u};
+// diagnostics (sn_conv_i8_path_counts): launches the folded kernel served, declined (bank not symmetric), sent to fp32
+__device__ unsigned long long g_fold_counts[4] = {0ull, 0ull, 0ull, 0ull};
 
 __device__ __forceinline__ float load_now(const float* p) {
     float v;
@@ -215,6 +230,199 @@ __device__ __forceinline__ uint32_t window(uint32_t hi, uint32_t lo) {   // byte
 #endif
 }
 
+// fp32 bank -> LDS, coalesced, one batch of loads; the first two tiles' halos are requested while those loads fly (the
+// other way round the bank's loads queue behind 24 DMA pieces per wave: vmcnt retires in order) and travel while the
+// tables are built
+__device__ __forceinline__ void stage_bank_and_first_halos(const Shape& s, const float* __restrict__ bank, int ntaps,
+                                                           float* bank_s, uint32_t* hbuf, int hdw,
+                                                           const uint8_t* __restrict__ x, int my_tiles, int tid, int wave,
+                                                           int lane) {
+    const int nb = s.G * ntaps;
+    constexpr int kB = 24;
+    for (int base = tid; base < nb; base += kThreads * kB) {
+        float v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int i = base + u * kThreads;
+            v[u] = bank[i < nb ? i : 0];
+        }
+        if (base == tid) {
+            const DmaLane dl = dma_lane(s, wave, lane);
+            if (my_tiles > 0) halo_dma_issue(hbuf, x, s, tile_coord(s, blockIdx.x), dl, wave);
+            if (my_tiles > 1) halo_dma_issue(hbuf + hdw, x, s, tile_coord(s, blockIdx.x + gridDim.x), dl, wave);
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int i = base + u * kThreads;
+            bank_s[i < nb ? i : nb] = v[u];
+        }
+    }
+}
+
+// Per kernel: max|W|, the fixed-point scale, the exact worst case of the quantisation error, and the fixed-point weight
+// Q = rint(W * S) written over W in bank_s (as int bits).  All 16 kernels at once: half a wave each (two passes of whole
+// waves took 4.7 us: two dependent reduction chains).
+__device__ __forceinline__ void quantise_kernels(const Shape& s, int ntaps, float* bank_s, float* scale, double* bnd,
+                                                 int wave, int lane) {
+    static_assert(2 * kWaves == 16, "one half wave per kernel");
+    const int g = 2 * wave + (lane >> 5), l32 = lane & 31;
+    float m = 0.0f;
+    if (g < s.G)
+        for (int t = l32; t < ntaps; t += 32) {
+            const float a = fabsf(bank_s[g * ntaps + t]);
+            m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);   // NaN / inf poisons the kernel
+        }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const float u = __shfl_xor(m, o, 64);
+        m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
+    }
+    const double S = (m > 0.0f) ? kQMax / (double)m : 0.0;   // NaN: comparisons false -> S = 0, scale = NaN below
+    const double invS = (double)m / kQMax;   // Q * invS instead of Q / S: 2e-16 relative, nothing next to the errors summed
+    double ep = 0.0, en = 0.0;
+    if (g < s.G && m > 0.0f)
+        for (int t = l32; t < ntaps; t += 32) {
+            const double w = (double)bank_s[g * ntaps + t];
+            const int Q = __double2int_rn(w * S);
+            const double e = (double)Q * invS - w;
+            ep += e > 0.0 ? e : 0.0;
+            en += e < 0.0 ? -e : 0.0;
+            bank_s[g * ntaps + t] = __int_as_float(Q);   // the table builds read the fixed-point weight, not W
+        }
+    else if (g < s.G)
+        for (int t = l32; t < ntaps; t += 32) bank_s[g * ntaps + t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        ep += __shfl_xor(ep, o, 64);
+        en += __shfl_xor(en, o, 64);
+    }
+    if (l32 == 0) {
+        scale[g] = (m != m) ? m : (float)((double)m / kQMax);
+        bnd[g] = ep > en ? ep : en;
+    }
+}
+
+// the guard's decision: all workgroups take it from the same numbers
+template <typename OT>
+__device__ __forceinline__ bool bound_exceeded(const Shape& s, const double* bnd, const float* __restrict__ lambdas,
+                                               const OT* act, const OT* out) {
+    if (!(s.tol > 0.0f)) return false;
+    double worst = 0.0, mixed = 0.0;
+    for (int g = 0; g < s.G; ++g) {
+        worst = bnd[g] > worst ? bnd[g] : worst;
+        if (out) mixed += fabs((double)lambdas[g]) * bnd[g];   // tanh and relu are 1-Lipschitz
+    }
+    return (act && worst > (double)s.tol) || (out && mixed > (double)s.tol);
+}
+
+// One round's epilogue, shared by the kernels of this file: recombine the three digit sums, store the bank activations
+// (if requested), mix the 16 kernels into the head.  acc[d][v]: digit plane d of accumulator tile v = 4 h + r.
+template <typename OT>
+__device__ __forceinline__ void finish_round(const Shape& s, const TileCoord& c, int lz, int lx, int n, int q,
+                                             i32x4 (&acc)[3][NV], const float* scale, const float* lamsc,
+                                             const float* lamhi, OT* __restrict__ act, OT* __restrict__ out, size_t V) {
+    const int gz = c.z0 + lz;
+    if (gz >= s.Z) return;
+    if (s.dbg & 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(acc[d][v]));
+        return;
+    }
+    const int gy4 = c.y0 + 4 * n;   // this lane's four residues: y = gy4 .. gy4 + 3
+    float pm[NV];                   // this lane group's share of the head's mix, per tile
+    const float4 lam4 = *reinterpret_cast<const float4*>(lamsc + 4 * q);
+    const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
+    if (act) {
+        // bank activations requested: every (kernel, voxel) value is formed, stored, and mixed
+        float val[NV][4];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int low = acc[1][v][r] * 256 + acc[0][v][r];   // |.| < 2^25: exact
+                val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);
+            }
+        const float4 sc4 = *reinterpret_cast<const float4*>(scale + 4 * q);
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+        if (gy4 < s.Y) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int gx = c.x0 + lx + h;
+                if (gx < s.X) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int g = 4 * q + r;
+                        if (g < s.G) {
+                            OT* o = act + ((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy4;
+                            const float v0 = val[4 * h + 0][r] * sc[r], v1 = val[4 * h + 1][r] * sc[r],
+                                        v2 = val[4 * h + 2][r] * sc[r], v3 = val[4 * h + 3][r] * sc[r];
+                            if constexpr (sizeof(OT) == 4) {
+                                *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
+                            } else {
+                                reinterpret_cast<double2*>(o)[0] = make_double2((double)v0, (double)v1);
+                                reinterpret_cast<double2*>(o)[1] = make_double2((double)v2, (double)v3);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    {
+        // the head's mix: sum_r lam_r (low_r + 65536 hi_r) as two packed FMAs per kernel and PAIR of tiles, straight
+        // from the integer accumulators (the same bits with or without `act`) -- 128 VALU per round instead of 164 (a VALU instruction costs the SIMD about
+        // 2.5 cycles next to a busy matrix pipe: tools/micro/mfma_valu_mix.hip)
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        const float4 hi4 = *reinterpret_cast<const float4*>(lamhi + 4 * q);
+        const float lhi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int vp = 0; vp < NV / 2; ++vp) {
+            const int v0 = 2 * vp, v1 = 2 * vp + 1;
+            f32x2 p = {0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int low0 = acc[1][v0][r] * 256 + acc[0][v0][r], low1 = acc[1][v1][r] * 256 + acc[0][v1][r];
+                const f32x2 lo = {(float)low0, (float)low1};
+                const f32x2 hi = {(float)acc[2][v0][r], (float)acc[2][v1][r]};
+                p = __builtin_elementwise_fma(f32x2{lam[r], lam[r]}, lo, p);
+                p = __builtin_elementwise_fma(f32x2{lhi[r], lhi[r]}, hi, p);
+            }
+            pm[v0] = p.x;
+            pm[v1] = p.y;
+        }
+    }
+    if (out) {
+        // sum over the four lane groups (the 16 kernels) with half / row swaps: one v_permlane32_swap + add sums
+        // TWO tiles over lanes (l, l + 32) -- tile a ends in the lower half, b in the upper --, one
+        // v_permlane16_swap + add does the same inside the halves.  Lane group q ends up holding exactly what it
+        // stores: x-row q >> 1, residues 2 (q & 1) and 2 (q & 1) + 1 (12 VALU; eight ds_bpermute pairs before).
+        auto sum_halves = [&](float a, float b) -> float {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+            return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        };
+        auto sum_rows = [&](float u, float w) -> float {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+            return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        };
+        const float e0 = sum_rows(sum_halves(pm[0], pm[4]), sum_halves(pm[2], pm[6]));   // rows: tiles 0 2 4 6
+        const float e1 = sum_rows(sum_halves(pm[1], pm[5]), sum_halves(pm[3], pm[7]));   // rows: tiles 1 3 5 7
+        const int h = q >> 1;
+        const int gx = c.x0 + lx + h, gy = gy4 + 2 * (q & 1);
+        if (gx < s.X && gy < s.Y) {
+            // wave-uniform row base (scalar arithmetic) + a 32-bit lane offset: no 64-bit vector address math per round
+            OT* row = out + ((size_t)c.b * V + ((size_t)gz * s.X + (c.x0 + lx)) * s.Y + c.y0);
+            OT* o = row + (unsigned)(h * s.Y + 4 * n + 2 * (q & 1));
+            float t0 = e0, t1 = e1;
+            if (s.head & 1) { t0 += (float)load_now(o); t1 += (float)load_now(o + 1); }
+            if (s.head & 2) { t0 = relu_tanh(t0); t1 = relu_tanh(t1); }
+            if constexpr (sizeof(OT) == 4) *reinterpret_cast<float2*>(o) = make_float2(t0, t1);
+            else *reinterpret_cast<double2*>(o) = make_double2((double)t0, (double)t1);
+        }
+    }
+}
+
 #ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING OUT=build/timing OBJDIR=build/obj_timing; read by tools/i8s_timing.py
 __device__ unsigned long long g_i8s_t[1024 * 16];
 __device__ unsigned long long g_i8s_w[1024 * 8 * 8];   // [workgroup][wave][phase]: summed wall_clock64 ticks (10 ns)
@@ -279,88 +487,20 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     if (tid < 2 * 4 * kMaxRQ) plan_s[tid] = reinterpret_cast<const short*>(&s.plan)[tid];
     const short* plan_halo = plan_s;                  // [4][kMaxRQ]
     const short* plan_tap = plan_s + 4 * kMaxRQ;      // [4][kMaxRQ]
-    {   // fp32 bank -> LDS, coalesced, one batch of loads; the first two tiles' halos are requested while those loads fly
-        // (the other way round the bank's loads queue behind 24 DMA pieces per wave: vmcnt retires in order) and
-        // travel while the tables are built
-        const int nb = s.G * ntaps;
-        constexpr int kB = 24;
-        for (int base = tid; base < nb; base += kThreads * kB) {
-            float v[kB];
-#pragma unroll
-            for (int u = 0; u < kB; ++u) {
-                const int i = base + u * kThreads;
-                v[u] = bank[i < nb ? i : 0];
-            }
-            if (base == tid) {
-                const DmaLane dl = dma_lane(s, wave, lane);
-                if (my_tiles > 0) halo_dma_issue(hbuf, x, s, tile_coord(s, blockIdx.x), dl, wave);
-                if (my_tiles > 1) halo_dma_issue(hbuf + hdw, x, s, tile_coord(s, blockIdx.x + gridDim.x), dl, wave);
-            }
-#pragma unroll
-            for (int u = 0; u < kB; ++u) {
-                const int i = base + u * kThreads;
-                bank_s[i < nb ? i : nb] = v[u];
-            }
-        }
-    }
+    stage_bank_and_first_halos(s, bank, ntaps, bank_s, hbuf, hdw, x, my_tiles, tid, wave, lane);
     lds_barrier();
     SN_ST(1);
-    // ---- per kernel: max|W|, the fixed-point scale, and the exact worst case of the quantisation error
-    {   // all 16 kernels at once: half a wave each (two passes of whole waves took 4.7 us: two dependent reduction chains)
-        static_assert(2 * kWaves == 16, "one half wave per kernel");
-        const int g = 2 * wave + (lane >> 5), l32 = lane & 31;
-        float m = 0.0f;
-        if (g < s.G)
-            for (int t = l32; t < ntaps; t += 32) {
-                const float a = fabsf(bank_s[g * ntaps + t]);
-                m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);   // NaN / inf poisons the kernel
-            }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            const float u = __shfl_xor(m, o, 64);
-            m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
-        }
-        const double S = (m > 0.0f) ? kQMax / (double)m : 0.0;   // NaN: comparisons false -> S = 0, scale = NaN below
-        const double invS = (double)m / kQMax;   // Q * invS instead of Q / S: 2e-16 relative, nothing next to the errors summed
-        double ep = 0.0, en = 0.0;
-        if (g < s.G && m > 0.0f)
-            for (int t = l32; t < ntaps; t += 32) {
-                const double w = (double)bank_s[g * ntaps + t];
-                const int Q = __double2int_rn(w * S);
-                const double e = (double)Q * invS - w;
-                ep += e > 0.0 ? e : 0.0;
-                en += e < 0.0 ? -e : 0.0;
-                bank_s[g * ntaps + t] = __int_as_float(Q);   // the table build below reads the fixed-point weight, not W
-            }
-        else if (g < s.G)
-            for (int t = l32; t < ntaps; t += 32) bank_s[g * ntaps + t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            ep += __shfl_xor(ep, o, 64);
-            en += __shfl_xor(en, o, 64);
-        }
-        if (l32 == 0) {
-            scale[g] = (m != m) ? m : (float)((double)m / kQMax);
-            bnd[g] = ep > en ? ep : en;
-        }
-    }
+    quantise_kernels(s, ntaps, bank_s, scale, bnd, wave, lane);
     lds_barrier();
     SN_ST(2);
     // ---- route: all workgroups take the same decision from the same numbers
-    if (s.tol > 0.0f) {
-        double worst = 0.0, mixed = 0.0;
-        for (int g = 0; g < s.G; ++g) {
-            worst = bnd[g] > worst ? bnd[g] : worst;
-            if (out) mixed += fabs((double)lambdas[g]) * bnd[g];   // tanh and relu are 1-Lipschitz
-        }
-        const bool exceeded = (act && worst > (double)s.tol) || (out && mixed > (double)s.tol);
+    {
+        const bool exceeded = bound_exceeded<OT>(s, bnd, lambdas, act, out);
         if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
         if (exceeded) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
             return;
         }
-    } else if (blockIdx.x == 0 && tid == 0 && s.route) {
-        *s.route = 0;
     }
     // ---- digit table Wd[st][d][l = (qq, g)]: 4 dwords j, slot (st, qq, j)
     //   pair step st < NP:   j = 2 e + c  ->  taps 4c .. 4c+3 of row 2 st + e of lane group qq
@@ -727,106 +867,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
             SN_WT(2, t_r2);
             const unsigned long long t_r3 = SN_WNOW();
             // ---- epilogue: recombine the digits, bank activations, head
-            const int gz = c.z0 + lz;
-            if (gz >= s.Z) continue;
-            if (s.dbg & 1) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(acc[d][v]));
-                continue;
-            }
-            const int gy4 = c.y0 + 4 * n;   // this lane's four residues: y = gy4 .. gy4 + 3
-            float pm[NV];                   // this lane group's share of the head's mix, per tile
-            const float4 lam4 = *reinterpret_cast<const float4*>(lamsc + 4 * q);
-            const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
-            if (act) {
-                // bank activations requested: every (kernel, voxel) value is formed, stored, and mixed
-                float val[NV][4];
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int low = acc[1][v][r] * 256 + acc[0][v][r];   // |.| < 2^25: exact
-                        val[v][r] = fmaf((float)acc[2][v][r], 65536.0f, (float)low);
-                    }
-                const float4 sc4 = *reinterpret_cast<const float4*>(scale + 4 * q);
-                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-                if (gy4 < s.Y) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int gx = c.x0 + lx + h;
-                        if (gx < s.X) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int g = 4 * q + r;
-                                if (g < s.G) {
-                                    OT* o = act + ((size_t)c.b * s.Gtot + s.g0 + g) * V + ((size_t)gz * s.X + gx) * s.Y + gy4;
-                                    const float v0 = val[4 * h + 0][r] * sc[r], v1 = val[4 * h + 1][r] * sc[r],
-                                                v2 = val[4 * h + 2][r] * sc[r], v3 = val[4 * h + 3][r] * sc[r];
-                                    if constexpr (sizeof(OT) == 4) {
-                                        *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
-                                    } else {
-                                        reinterpret_cast<double2*>(o)[0] = make_double2((double)v0, (double)v1);
-                                        reinterpret_cast<double2*>(o)[1] = make_double2((double)v2, (double)v3);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            {
-                // the head's mix: sum_r lam_r (low_r + 65536 hi_r) as two packed FMAs per kernel and PAIR of tiles, straight
-                // from the integer accumulators (the same bits with or without `act`) -- 128 VALU per round instead of 164 (a VALU instruction costs the SIMD about
-                // 2.5 cycles next to a busy matrix pipe: tools/micro/mfma_valu_mix.hip)
-                using f32x2 = __attribute__((ext_vector_type(2))) float;
-                const float4 hi4 = *reinterpret_cast<const float4*>(lamhi + 4 * q);
-                const float lhi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-                for (int vp = 0; vp < NV / 2; ++vp) {
-                    const int v0 = 2 * vp, v1 = 2 * vp + 1;
-                    f32x2 p = {0.0f, 0.0f};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int low0 = acc[1][v0][r] * 256 + acc[0][v0][r], low1 = acc[1][v1][r] * 256 + acc[0][v1][r];
-                        const f32x2 lo = {(float)low0, (float)low1};
-                        const f32x2 hi = {(float)acc[2][v0][r], (float)acc[2][v1][r]};
-                        p = __builtin_elementwise_fma(f32x2{lam[r], lam[r]}, lo, p);
-                        p = __builtin_elementwise_fma(f32x2{lhi[r], lhi[r]}, hi, p);
-                    }
-                    pm[v0] = p.x;
-                    pm[v1] = p.y;
-                }
-            }
-            if (out) {
-                // sum over the four lane groups (the 16 kernels) with half / row swaps: one v_permlane32_swap + add sums
-                // TWO tiles over lanes (l, l + 32) -- tile a ends in the lower half, b in the upper --, one
-                // v_permlane16_swap + add does the same inside the halves.  Lane group q ends up holding exactly what it
-                // stores: x-row q >> 1, residues 2 (q & 1) and 2 (q & 1) + 1 (12 VALU; eight ds_bpermute pairs before).
-                auto sum_halves = [&](float a, float b) -> float {
-                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                };
-                auto sum_rows = [&](float u, float w) -> float {
-                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
-                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                };
-                const float e0 = sum_rows(sum_halves(pm[0], pm[4]), sum_halves(pm[2], pm[6]));   // rows: tiles 0 2 4 6
-                const float e1 = sum_rows(sum_halves(pm[1], pm[5]), sum_halves(pm[3], pm[7]));   // rows: tiles 1 3 5 7
-                const int h = q >> 1;
-                const int gx = c.x0 + lx + h, gy = gy4 + 2 * (q & 1);
-                if (gx < s.X && gy < s.Y) {
-                    // wave-uniform row base (scalar arithmetic) + a 32-bit lane offset: no 64-bit vector address math per round
-                    OT* row = out + ((size_t)c.b * V + ((size_t)gz * s.X + (c.x0 + lx)) * s.Y + c.y0);
-                    OT* o = row + (unsigned)(h * s.Y + 4 * n + 2 * (q & 1));
-                    float t0 = e0, t1 = e1;
-                    if (s.head & 1) { t0 += (float)load_now(o); t1 += (float)load_now(o + 1); }
-                    if (s.head & 2) { t0 = relu_tanh(t0); t1 = relu_tanh(t1); }
-                    if constexpr (sizeof(OT) == 4) *reinterpret_cast<float2*>(o) = make_float2(t0, t1);
-                    else *reinterpret_cast<double2*>(o) = make_double2((double)t0, (double)t1);
-                }
-            }
+            finish_round<OT>(s, c, lz, lx, n, q, acc, scale, lamsc, lamhi, act, out, V);
             SN_WT(3, t_r3);
         }
         // ---- this wave is through with tile `it`
@@ -843,6 +884,338 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     }
     if (!healthy && lane == 0) flags[1] = 1;
     SN_ST(5);
+}
+
+// ================================================================================================ folded kernel
+// GENEO kernels are radial in (x, y) (cylinder.py:152-176, arrow.py:214-252, neg_sphere.py:166-199): W[dz][dx][dy] =
+// W[dz][8-dx][dy] = W[dz][dx][8-dy], bit for bit (the generators evaluate the same expression on (dx-4)^2 + (dy-4)^2).
+// For such a bank
+//     sum_{dx,dy} W[dz][dx][dy] x[.., x+dx, y+dy]  =  sum_{dx'<=4, dy'<=4} W[dz][dx'][dy'] F[dz][dx'][dy'],
+//     F = the sum of x over the orbit {dx', 8-dx'} x {dy', 8-dy'}  (1, 2 or 4 voxels: 0..4, exact in int8),
+// i.e. 9 x 5 x 5 = 225 taps instead of 729 with EXACTLY the same integer sums -- 4 MFMA steps per 16 x 16 outputs instead
+// of 12.  The folding is done on the way from LDS to the B operand: the two halo rows of a folded row are added dword by
+// dword (bytes <= 2, no carries), the y window of residue r folds as  v_alignbyte(R1, R0, r) + v_perm(R2:R1, bytes r+8 ..
+// r+5)  (bytes <= 4), and the centre taps dy' = 4 (byte r of R1) of a step's three rows are packed by the 4 x 4 byte
+// transpose the stride-4 kernel uses for tap 8.  A step = 3 folded rows + their centre dword per lane group; 45 folded rows
+// (+ 3 pads) over 4 lane groups x 12 slots.  Everything else -- halo ring, LDS-DMA, claimed rounds, quantisation, guard,
+// epilogue -- is the stride-4 kernel's.  The prologue CHECKS the symmetry on the fp32 weights (bitwise); a bank that is not
+// symmetric is not served here: *route = 2 sends the launch to the stride-4 kernel enqueued behind this one.
+template <typename OT>
+__global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* __restrict__ x,
+                                                                const float* __restrict__ bank,
+                                                                const float* __restrict__ lambdas, Shape s,
+                                                                OT* __restrict__ act, OT* __restrict__ out) {
+    if (!s.gate.pass()) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    constexpr int ntaps = 729;
+    const int hrows = s.ZP * s.XP;
+    const int hdw = hrows * DW;
+    // LDS carve-up
+    uint4* Wd = reinterpret_cast<uint4*>(lds);                                   // [kFoldSteps][3][64] x 16 B
+    int4* foff = reinterpret_cast<int4*>(Wd + (size_t)kFoldSteps * 3 * 64);      // [kFoldSteps][4][2]: byte offsets (h1, h2) of rows 0, 1 | row 2
+    float* scale = reinterpret_cast<float*>(foff + kFoldSteps * 4 * 2);          // [16]
+    float* lamsc = scale + 16;                                                   // [16]
+    float* lamhi = lamsc + 16;                                                   // [16] (+ 64 bytes spare)
+    double* bnd = reinterpret_cast<double*>(lamhi + 32);                         // [16]
+    int* landed = reinterpret_cast<int*>(bnd + 16);                              // [kNB]
+    int* done = landed + 4;                                                      // [kNB]
+    int* flags = done + 4;                                                       // [4]  1: a spin gave up, 2: the bank is not symmetric
+    int* rclaim = flags + 4;                                                     // [kNB]
+    short* plan_s = reinterpret_cast<short*>(rclaim + 4);                        // FoldPlan copy
+    uint32_t* hbuf = reinterpret_cast<uint32_t*>(plan_s + 3 * 4 * kFoldSlots);   // [kNB][hdw]
+    float* bank_s = reinterpret_cast<float*>(hbuf + (size_t)2 * hdw);            // prologue only: over ring slot 2 and beyond
+
+    const int my_tiles = (int)blockIdx.x < s.ntiles ? (s.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (tid < 16) landed[tid] = 0;
+    if (tid < 3 * 4 * kFoldSlots) plan_s[tid] = reinterpret_cast<const short*>(&s.fplan)[tid];
+    const short* plan_h1 = plan_s;
+    const short* plan_h2 = plan_s + 4 * kFoldSlots;
+    const short* plan_tap = plan_s + 2 * 4 * kFoldSlots;
+    stage_bank_and_first_halos(s, bank, ntaps, bank_s, hbuf, hdw, x, my_tiles, tid, wave, lane);
+    lds_barrier();
+    // ---- is every kernel symmetric in x and in y?  (bitwise on the fp32 weights; a NaN pattern compares like any other)
+    {
+        bool asym = false;
+        const uint32_t* wb = reinterpret_cast<const uint32_t*>(bank_s);
+        for (int i = tid; i < s.G * ntaps; i += kThreads) {
+            const int t = i % ntaps, g = i / ntaps;
+            const int dy = t % 9, dx = (t / 9) % 9, dz = t / 81;
+            const uint32_t w = wb[i];
+            asym |= w != wb[g * ntaps + (dz * 9 + (8 - dx)) * 9 + dy];
+            asym |= w != wb[g * ntaps + (dz * 9 + dx) * 9 + (8 - dy)];
+        }
+        if (asym) flags[2] = 1;   // benign race: every writer stores 1
+    }
+    lds_barrier();
+    if (flags[2]) {
+        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = 2;
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_fold_counts[1], 1ull);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
+        return;
+    }
+    quantise_kernels(s, ntaps, bank_s, scale, bnd, wave, lane);
+    lds_barrier();
+    {
+        const bool exceeded = bound_exceeded<OT>(s, bnd, lambdas, act, out);
+        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_fold_counts[exceeded ? 2 : 0], 1ull);
+        if (exceeded) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+    }
+    // ---- digit table Wd[st][d][l = (qq, g)]: dword j < 3: taps dy' = 0..3 of the lane group's row (st, j); dword 3: tap
+    // dy' = 4 of rows (st, 0..2) in bytes 0..2
+    for (int i = tid; i < kFoldSteps * 64; i += kThreads) {
+        const int l = i & 63, st = i >> 6;
+        const int g = l & 15, qq = l >> 4;
+        uint32_t w0[4] = {0u, 0u, 0u, 0u}, w1[4] = {0u, 0u, 0u, 0u}, w2[4] = {0u, 0u, 0u, 0u};
+        if (g < s.G) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int slot = st * kFoldRows + (j < 3 ? j : b);
+                    const int krow = (j == 3 && b == 3) ? -1 : plan_tap[qq * kFoldSlots + (j == 3 && b == 3 ? 0 : slot)];
+                    const int dy = j < 3 ? b : 4;
+                    int Q = __float_as_int(bank_s[g * ntaps + (krow < 0 ? 0 : krow) * 9 + dy]);
+                    Q = krow < 0 ? 0 : Q;
+                    const int d0 = ((Q + 128) & 255) - 128;
+                    Q = (Q - d0) >> 8;
+                    const int d1 = ((Q + 128) & 255) - 128;
+                    const int d2 = (Q - d1) >> 8;
+                    w0[j] |= (uint32_t)(d0 & 255) << (8 * b);
+                    w1[j] |= (uint32_t)(d1 & 255) << (8 * b);
+                    w2[j] |= (uint32_t)(d2 & 255) << (8 * b);
+                }
+        }
+        Wd[(st * 3 + 0) * 64 + l] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+        Wd[(st * 3 + 1) * 64 + l] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        Wd[(st * 3 + 2) * 64 + l] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+    }
+    for (int i = tid; i < kFoldSteps * 4; i += kThreads) {
+        const int qq = i & 3, st = i >> 2;
+        const short* a = plan_h1 + qq * kFoldSlots + st * kFoldRows;
+        const short* b = plan_h2 + qq * kFoldSlots + st * kFoldRows;
+        foff[i * 2 + 0] = make_int4(a[0] * (DW * 4), b[0] * (DW * 4), a[1] * (DW * 4), b[1] * (DW * 4));
+        foff[i * 2 + 1] = make_int4(a[2] * (DW * 4), b[2] * (DW * 4), 0, 0);
+    }
+    if (tid < 16) {
+        const float ls = (out && tid < s.G) ? lambdas[tid] * scale[tid] : 0.0f;
+        lamsc[tid] = ls;
+        lamhi[tid] = 65536.0f * ls;
+    }
+    if (my_tiles == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int half_tx = s.TX >> 1;
+    const int hx_shift = 31 - __builtin_clz(half_tx);
+    const int nrounds = s.TZ * half_tx;
+    const size_t V = (size_t)s.Z * s.X * s.Y;
+    bool healthy = true;
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = blockIdx.x + it * gridDim.x;
+        const TileCoord c = tile_coord(s, tile);
+        const int bi = it % kNB;
+        const uint8_t* hb = reinterpret_cast<const uint8_t*>(hbuf + (size_t)bi * hdw);
+        if (it >= 2) healthy &= wave_wait(&landed[bi], kWaves * (it / kNB + 1 - (bi < 2 ? 1 : 0)));
+        const bool dma_next = it + 2 < my_tiles;
+        bool dma_pending = dma_next;
+        auto dma_ahead = [&]() {
+            const int bn = (it + 2) % kNB;
+            if (it >= 1) healthy &= wave_wait(&done[bn], kWaves * ((it - 1) / kNB + 1));
+            halo_dma_issue(hbuf + (size_t)bn * hdw, x, s, tile_coord(s, tile + 2 * gridDim.x), dma_lane(s, wave, lane), wave);
+            dma_pending = false;
+        };
+        const int ticket0 = (it / kNB) * (nrounds + kWaves);
+        auto claim = [&]() -> int {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&rclaim[bi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return __builtin_amdgcn_readfirstlane(t) - ticket0;
+        };
+        const int k_dma = nrounds >= 3 * kWaves ? 2 : 1;
+        int k = 0, next = 0;
+        for (int round = claim(); round < nrounds; round = next, ++k) {
+            next = claim();
+            if (k == k_dma && dma_pending) dma_ahead();
+            const int lz = round >> hx_shift, lx = (round & (half_tx - 1)) * 2;
+            const uint8_t* xb = hb + ((lz * s.XP + lx) * DW + n + D0) * 4;
+
+            i32x4 acc[3][NV];
+            auto load_w = [&](int st, i32x4 (&w)[3]) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint4 u = Wd[(st * 3 + d) * 64 + lane];
+                    w[d] = i32x4{(int)u.x, (int)u.y, (int)u.z, (int)u.w};
+                }
+            };
+            auto mma_tile = [&](const i32x4 (&w)[3], const i32x4& xv, int v, bool first) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv, first ? i32x4{0, 0, 0, 0} : acc[d][v], 0, 0, 0);
+            };
+            // raw dwords of one (row j, x-row h) unit: halo row h1 in r[0..2], h2 in r[3..5] (dwords D0 D1 D2)
+            auto load_unit = [&](int off1, int off2, int h, bool single, uint32_t (&r)[6]) {
+                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(xb + off1 + h * (DW * 4));
+                r[0] = p1[0]; r[1] = p1[1]; r[2] = p1[2];
+                if (!single) {
+                    const uint32_t* p2 = reinterpret_cast<const uint32_t*>(xb + off2 + h * (DW * 4));
+                    r[3] = p2[0]; r[4] = p2[1]; r[5] = p2[2];
+                }
+            };
+            // fold one unit into component J of the four residues' operand quads X[r] (a step's B operand for tile (h, r) is
+            // the quad (row 0, row 1, row 2, centres): written in place, component by component); also returns the summed
+            // dword 1, whose byte r is the centre tap of residue r
+            auto fold_unit = [&](const uint32_t (&r)[6], bool single, auto JC, i32x4 (&X)[4], uint32_t& centre) {
+                constexpr int J = decltype(JC)::value;
+                const uint32_t R0 = single ? r[0] : r[0] + r[3];
+                const uint32_t R1 = single ? r[1] : r[1] + r[4];
+                const uint32_t R2 = single ? r[2] : r[2] + r[5];
+                X[0][J] = (int)(R0 + __builtin_amdgcn_perm(R2, R1, 0x01020304u));
+                X[1][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 1) + __builtin_amdgcn_perm(R2, R1, 0x02030405u));
+                X[2][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 2) + __builtin_amdgcn_perm(R2, R1, 0x03040506u));
+                X[3][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 3) + __builtin_amdgcn_perm(R2, R1, 0x04050607u));
+                centre = R1;
+            };
+            auto centres = [&](uint32_t c0, uint32_t c1, uint32_t c2, i32x4 (&X)[4]) {
+                uint32_t o[4];
+                transpose4(c0, c1, c2, 0u, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[r][3] = (int)o[r];
+            };
+            constexpr std::integral_constant<int, 0> J0{};
+            constexpr std::integral_constant<int, 1> J1{};
+            constexpr std::integral_constant<int, 2> J2{};
+            // operands of one step: X[h][r], un-pipelined form (a round's first step)
+            auto build_step = [&](auto ST, i32x4 (&X)[2][4]) {
+                constexpr int st = decltype(ST)::value;
+                const int4 o01 = foff[(st * 4 + q) * 2], o2 = foff[(st * 4 + q) * 2 + 1];
+                uint32_t c00, c01, c10, c11, c20, c21;
+                uint32_t r00[6], r01[6], r10[6], r11[6], r20[6], r21[6];
+                load_unit(o01.x, o01.y, 0, fold_slot_single(st, 0), r00);
+                load_unit(o01.x, o01.y, 1, fold_slot_single(st, 0), r01);
+                load_unit(o01.z, o01.w, 0, fold_slot_single(st, 1), r10);
+                load_unit(o01.z, o01.w, 1, fold_slot_single(st, 1), r11);
+                load_unit(o2.x, o2.y, 0, fold_slot_single(st, 2), r20);
+                load_unit(o2.x, o2.y, 1, fold_slot_single(st, 2), r21);
+                fold_unit(r00, fold_slot_single(st, 0), J0, X[0], c00);
+                fold_unit(r01, fold_slot_single(st, 0), J0, X[1], c01);
+                fold_unit(r10, fold_slot_single(st, 1), J1, X[0], c10);
+                fold_unit(r11, fold_slot_single(st, 1), J1, X[1], c11);
+                fold_unit(r20, fold_slot_single(st, 2), J2, X[0], c20);
+                fold_unit(r21, fold_slot_single(st, 2), J2, X[1], c21);
+                centres(c00, c10, c20, X[0]);
+                centres(c01, c11, c21, X[1]);
+            };
+            auto mma_step = [&](const i32x4 (&w)[3], const i32x4 (&X)[2][4], bool first, auto&& work) {
+                auto group = [&](auto VC) {   // (compile-time v: the pieces index registers, never memory)
+                    constexpr int v = decltype(VC)::value, h = v >> 2, r = v & 3;
+                    mma_tile(w, X[h][r], v, first);
+                    __builtin_amdgcn_sched_barrier(0);
+                    work(VC);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{});
+                group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+                group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+                group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
+            };
+            // the next step's operands, built in eight pieces behind the eight MFMA groups of the current step: pieces
+            // 0..5 fold unit (j, h) = (piece >> 1, piece & 1) whose raw dwords were requested two pieces earlier, pieces 6, 7
+            // transpose the centres of x-row 0, 1
+            uint32_t praw[6][6], pcen[3][2];
+            int4 po01, po2;
+            auto pipe_open = [&](auto ST) {   // offsets and the first two units' raw dwords
+                constexpr int st = decltype(ST)::value;
+                po01 = foff[(st * 4 + q) * 2];
+                po2 = foff[(st * 4 + q) * 2 + 1];
+                load_unit(po01.x, po01.y, 0, fold_slot_single(st, 0), praw[0]);
+                load_unit(po01.x, po01.y, 1, fold_slot_single(st, 0), praw[1]);
+            };
+            auto pipe_piece = [&](auto ST, auto PC, i32x4 (&X)[2][4]) {
+                constexpr int st = decltype(ST)::value, piece = decltype(PC)::value;
+                if constexpr (piece + 2 < 6) {
+                    constexpr int u = piece + 2, j = u >> 1, h = u & 1;
+                    load_unit(j == 1 ? po01.z : po2.x, j == 1 ? po01.w : po2.y, h, fold_slot_single(st, j), praw[u]);
+                }
+                if constexpr (piece < 6) {
+                    constexpr int j = piece >> 1, h = piece & 1;
+                    fold_unit(praw[piece], fold_slot_single(st, j), std::integral_constant<int, j>{}, X[h], pcen[j][h]);
+                } else {
+                    constexpr int h = piece - 6;
+                    centres(pcen[0][h], pcen[1][h], pcen[2][h], X[h]);
+                }
+            };
+            constexpr std::integral_constant<int, 0> S0{};
+            constexpr std::integral_constant<int, 1> S1{};
+            constexpr std::integral_constant<int, 2> S2{};
+            constexpr std::integral_constant<int, 3> S3{};
+            i32x4 wa[3], wb[3];
+            i32x4 Xa[2][4], Xb[2][4];
+            load_w(0, wa);
+            build_step(S0, Xa);
+            load_w(1, wb);
+            pipe_open(S1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(wa, Xa, true, [&](auto v) { pipe_piece(S1, v, Xb); });
+            load_w(2, wa);
+            pipe_open(S2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(wb, Xb, false, [&](auto v) { pipe_piece(S2, v, Xa); });
+            load_w(3, wb);
+            pipe_open(S3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(wa, Xa, false, [&](auto v) { pipe_piece(S3, v, Xb); });
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(wb, Xb, false, [](auto) {});
+            finish_round<OT>(s, c, lz, lx, n, q, acc, scale, lamsc, lamhi, act, out, V);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_signal(&done[bi], lane);
+        if (dma_pending) dma_ahead();
+        if (dma_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_signal(&landed[(it + 2) % kNB], lane);
+        }
+    }
+    if (!healthy && lane == 0) flags[1] = 1;
+}
+
+size_t lds_bytes_fold(const Shape& s) {
+    const size_t hdw = (size_t)s.ZP * s.XP * DW;
+    const size_t ring = kNB * hdw * 4, alias = 2 * hdw * 4 + ((size_t)s.G * 729 + 1) * sizeof(float);
+    return (size_t)kFoldSteps * 3 * 64 * 16 + (size_t)kFoldSteps * 4 * 2 * 16 + 64 + 64 + 128 + 128 + 64 + sizeof(FoldPlan) +
+           (ring > alias ? ring : alias) + 16;
+}
+
+// 45 folded rows (dz, dx') -> 4 lane groups x 12 slots (see FoldPlan).  Lane groups (0, 1) and (2, 3) are served by one
+// LDS cycle each: at every slot their halo rows differ by 2 (mod 4) -- dz and dz + 2 at the same dx', or dx' and dx' + 2
+// at dz = 8 -- which is 16 banks with 24-dword rows, for h1 and for h2 alike.
+void plan_fold(int XP, FoldPlan& p) {
+    static const int dpos[9] = {0, 1, 3, 4, 6, 7, 9, 10, 11};   // double slots (st * 3 + j), in the order they are filled
+    static const int spos[3] = {2, 5, 8};                        // single slots
+    for (int qq = 0; qq < 4; ++qq) {
+        auto put = [&](int slot, int dz, int dxp, bool pad) {
+            p.h1[qq][slot] = (short)(dz * XP + dxp);
+            p.h2[qq][slot] = (short)(dz * XP + 8 - dxp);
+            p.tap[qq][slot] = pad ? (short)-1 : (short)(dz * 9 + dxp);
+        };
+        for (int i = 0; i < 8; ++i) put(dpos[i], 2 * qq + (i >> 2), i & 3, false);   // dz in {2q, 2q + 1}, dx' = 0..3
+        static const int last_dx[4] = {0, 2, 1, 3};
+        put(dpos[8], 8, last_dx[qq], false);
+        put(spos[0], 2 * qq, 4, false);        // (0,4) (2,4) (4,4) (6,4)
+        put(spos[1], 2 * qq + 1, 4, false);    // (1,4) (3,4) (5,4) (7,4)
+        static const int pad_dz[4] = {8, 6, 0, 2};
+        put(spos[2], pad_dz[qq], 4, qq != 0);  // (8,4), then pads on rows 2 (mod 4) apart pairwise
+    }
 }
 
 size_t lds_bytes(const Shape& s) {
@@ -958,13 +1331,45 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     if (!found) return 1;
     // quantisation guard (see the header): tolerance on the worst-case activation error of the int8 path
     s.tol = sn::option_conv_i8_tolerance();
-    s.route = nullptr;
-    if (s.tol > 0.0f) {
-        s.route = sn::device_flag_slot();
+    const int grid = cus < s.ntiles ? cus : s.ntiles;
+    // 1. the folded kernel (banks symmetric in x and y: every GENEO bank) -- it checks the symmetry on the device and leaves
+    //    *flag = 0 (served), 1 (bound exceeded: fp32 kernel) or 2 (not symmetric: the stride-4 kernel below)
+    const char* nofold = getenv("SN_CONV_I8_NOFOLD");
+    int32_t* flag = sn::device_flag_slot();
+    const bool fold = kz == 9 && kx == 9 && flag && !(nofold && nofold[0] == '1') && sn::option_conv_i8_fold() &&
+                      s.dbg == 0;   // (the debug switches belong to the stride-4 kernel)
+    bool folded = false;
+    if (fold) {
+        Shape sf = s;
+        plan_fold(sf.XP, sf.fplan);
+        sf.route = flag;
+        const size_t ldsf = lds_bytes_fold(sf);
+        if (ldsf <= (size_t)kMaxLds) {
+#define SN_LAUNCH_I8F(OT)                                                                                        \
+    do {                                                                                                         \
+        auto kern = conv_occ_i8f_kernel<OT>;                                                                     \
+        if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
+            return check_launch("sn_conv_bank(i8f: hipFuncSetAttribute)");                                       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), ldsf, stream, x, bank, lambdas, sf, (OT*)act,       \
+                           (OT*)out);                                                                            \
+    } while (0)
+            if (out_dtype == SN_F32) SN_LAUNCH_I8F(float);
+            else SN_LAUNCH_I8F(double);
+#undef SN_LAUNCH_I8F
+            if (int rc = check_launch("sn_conv_bank(i8f)")) return rc;
+            folded = true;
+        }
+    }
+    // 2. the stride-4 kernel: the whole job without the folded kernel, else only what it declined (*flag == 2)
+    s.route = folded ? flag : nullptr;
+    if (!folded && s.tol > 0.0f) {
+        s.route = flag;
         if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
     }
-    const int grid = cus < s.ntiles ? cus : s.ntiles;
-    const size_t lds = lds_bytes(s);
+    {
+        sn::GateScope declined(folded ? flag : nullptr, 2);
+        s.gate = sn::current_gate();
+        const size_t lds = lds_bytes(s);
 #define SN_LAUNCH_I8S(OT)                                                                                        \
     do {                                                                                                         \
         auto kern = conv_occ_i8s_kernel<OT, 10, 6, 1>;                                                           \
@@ -973,12 +1378,13 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, s, (OT*)act,         \
                            (OT*)out);                                                                            \
     } while (0)
-    if (out_dtype == SN_F32) SN_LAUNCH_I8S(float);
-    else SN_LAUNCH_I8S(double);
+        if (out_dtype == SN_F32) SN_LAUNCH_I8S(float);
+        else SN_LAUNCH_I8S(double);
 #undef SN_LAUNCH_I8S
-    if (int rc = check_launch("sn_conv_bank(i8s)")) return rc;
-    if (s.route) {
-        // the same launch on the fp32 matrix pipe, enqueued behind: runs only if the guard above sent it here
+        if (int rc = check_launch("sn_conv_bank(i8s)")) return rc;
+    }
+    if (s.route && s.tol > 0.0f) {
+        // 3. the same launch on the fp32 matrix pipe, enqueued behind: runs only if a guard above sent it here
         sn::GateScope guard(s.route, 1);
         return sn::conv_bank_group(x, SN_U8, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky, act, out,
                                    out_dtype, reinterpret_cast<sn_stream_t>(stream));
@@ -987,6 +1393,15 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
 }
 
 }  // namespace sn
+
+extern "C" int sn_conv_i8_path_counts(unsigned long long* counts3) {
+    if (!counts3) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_i8_path_counts: null pointer");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_counts), sizeof(h)) != hipSuccess)
+        return sn::check_launch("sn_conv_i8_path_counts");
+    counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[2];
+    return SN_OK;
+}
 
 #ifdef SN_CONV_TIMING
 extern "C" void sn_debug_i8s_times(unsigned long long* host) {
