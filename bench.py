@@ -258,9 +258,10 @@ def main():
         spin(lambda: step(False), args.spinup_ms)
     for _ in range(args.warmup):
         step(False)
+    served_before = sna._hip.conv_i8_path_counts()[0]   # launches the folded int8 kernel has served so far
+    event_every = args.event_every if args.event_every > 0 else (4 if args.steps >= 8 else 1)
     fence()
     t0 = time.perf_counter()
-    event_every = args.event_every if args.event_every > 0 else (4 if args.steps >= 8 else 1)
     for i_ in range(args.steps):
         out = step(i_ % event_every == 0)   # HIP events around the stages: on every --event-every'th timed step
     fence()
@@ -294,7 +295,14 @@ def main():
     # four-copy kernel (conv_i8.hip, everything else): ky padded to a multiple of 4 -> 243 dwords -> 16 steps
     stride4 = (KERNEL_SIZE[2] == 9 and KERNEL_SIZE[0] * KERNEL_SIZE[1] == 81 and args.grid % 16 == 0
                and not sna._hip.get_option("conv_i8_legacy"))
-    if stride4:
+    # folded kernel (conv_i8s.hip, conv_occ_i8f_kernel): a 9^3 bank that is symmetric in x and y -- every GENEO bank;
+    # the device checks it per call and counts what it served -- is contracted over 9 x 5 x 5 folded taps: 45 folded
+    # rows x 1 1/4 dwords -> 4 steps.  `achieved` keeps SURVEY 8d's dense convention (2 * V * 729 * 16 flops per tile).
+    served_now = sna._hip.conv_i8_path_counts()[0]
+    folded = stride4 and tuple(KERNEL_SIZE) == (9, 9, 9) and served_now - served_before >= args.steps
+    if folded:
+        i8_steps = 4
+    elif stride4:
         rq = (KERNEL_SIZE[0] * KERNEL_SIZE[1] + 3) // 4
         i8_steps = rq // 2 + ((rq + 3) // 4 + 2 * (rq & 1) + 3) // 4
     else:
@@ -455,11 +463,15 @@ def main():
         # dominant kernel.  `achieved` = ALGORITHMIC flops (2*V*729*16 per tile) / launch time; `peak` = dense int8
         # MFMA peak.  `executed` counts what the kernel really issues (3 digit planes x 64-slot steps): that is the
         # matrix-pipe utilisation figure.
-        "roofline": {"kernel": ("conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel") + " (K3', v_mfma_i32_16x16x64_i8)",
+        "roofline": {"kernel": ("conv_occ_i8f_kernel" if folded else "conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel")
+                               + " (K3', v_mfma_i32_16x16x64_i8)",
+                     "algorithm": ("bank symmetric in x and y (checked on the device per call): 9x5x5 folded taps, the same "
+                                   "integer sums as the 729-tap contraction" if folded else "729 taps per kernel"),
                      "bound": "mfma", "mfma_steps_per_16x16_outputs": i8_steps,
                      "achieved": conv_tflops, "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s",
                      "frac": conv_tflops / PEAK_I8_MFMA_TOPS,
-                     "traffic": traffic.get("conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel"),
+                     "traffic": traffic.get("conv_occ_i8f_kernel" if folded and "conv_occ_i8f_kernel" in traffic
+                                            else "conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel"),
                      "launch_ms": conv_ms, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops, "executed": executed_tops,
                      "executed_frac": executed_tops / PEAK_I8_MFMA_TOPS,
                      "executed_frac_of_measured_ceiling": executed_tops / MEASURED_I8_MFMA_TOPS},

@@ -900,7 +900,17 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 // (+ 3 pads) over 4 lane groups x 12 slots.  Everything else -- halo ring, LDS-DMA, claimed rounds, quantisation, guard,
 // epilogue -- is the stride-4 kernel's.  The prologue CHECKS the symmetry on the fp32 weights (bitwise); a bank that is not
 // symmetric is not served here: *route = 2 sends the launch to the stride-4 kernel enqueued behind this one.
-template <typename OT>
+// Compile-time halo pitch kXP (17 / 13 / 11 for TX = 8 / 4 / 2): the halo byte offset of a regular slot is
+//     q * (2 kXP 96) + (a kXP + dx') 96        (lane group q carries planes dz = 2 q + a, a = 0, 1),
+// one per-lane register plus an immediate of the LDS read -- no offset table, no address arithmetic in the rounds.  The two
+// irregular slots (8: the single of plane 8 and three pads; 11: plane 8's doubles) take their offsets from the plan.
+constexpr int fold_slot_a(int slot) { return slot >= 5 && slot != 8 && slot != 11 ? 1 : 0; }   // slots 0..4: a = 0; 5, 6, 7, 9, 10: a = 1
+constexpr int fold_slot_dx(int slot) {
+    return slot == 2 || slot == 5 ? 4 : slot == 0 || slot == 6 ? 0 : slot == 1 || slot == 7 ? 1 : slot == 3 || slot == 9 ? 2 : 3;
+}
+constexpr bool fold_slot_irregular(int slot) { return slot == 8 || slot == 11; }
+
+template <typename OT, int kXP>
 __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* __restrict__ x,
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ lambdas, Shape s,
@@ -915,8 +925,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
     const int hdw = hrows * DW;
     // LDS carve-up
     uint4* Wd = reinterpret_cast<uint4*>(lds);                                   // [kFoldSteps][3][64] x 16 B
-    int4* foff = reinterpret_cast<int4*>(Wd + (size_t)kFoldSteps * 3 * 64);      // [kFoldSteps][4][2]: byte offsets (h1, h2) of rows 0, 1 | row 2
-    float* scale = reinterpret_cast<float*>(foff + kFoldSteps * 4 * 2);          // [16]
+    float* scale = reinterpret_cast<float*>(Wd + (size_t)kFoldSteps * 3 * 64);   // [16]
     float* lamsc = scale + 16;                                                   // [16]
     float* lamhi = lamsc + 16;                                                   // [16] (+ 64 bytes spare)
     double* bnd = reinterpret_cast<double*>(lamhi + 32);                         // [16]
@@ -996,13 +1005,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         Wd[(st * 3 + 1) * 64 + l] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
         Wd[(st * 3 + 2) * 64 + l] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
     }
-    for (int i = tid; i < kFoldSteps * 4; i += kThreads) {
-        const int qq = i & 3, st = i >> 2;
-        const short* a = plan_h1 + qq * kFoldSlots + st * kFoldRows;
-        const short* b = plan_h2 + qq * kFoldSlots + st * kFoldRows;
-        foff[i * 2 + 0] = make_int4(a[0] * (DW * 4), b[0] * (DW * 4), a[1] * (DW * 4), b[1] * (DW * 4));
-        foff[i * 2 + 1] = make_int4(a[2] * (DW * 4), b[2] * (DW * 4), 0, 0);
-    }
     if (tid < 16) {
         const float ls = (out && tid < s.G) ? lambdas[tid] * scale[tid] : 0.0f;
         lamsc[tid] = ls;
@@ -1020,6 +1022,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
     const int nrounds = s.TZ * half_tx;
     const size_t V = (size_t)s.Z * s.X * s.Y;
     bool healthy = true;
+    // per-lane halo offsets: the lane group's planes, and the two irregular slots
+    const int qbase = q * (2 * kXP * DW * 4);
+    const int ir8 = plan_h1[q * kFoldSlots + 8] * (DW * 4);
+    const int ir11a = plan_h1[q * kFoldSlots + 11] * (DW * 4), ir11b = plan_h2[q * kFoldSlots + 11] * (DW * 4);
 
     for (int it = 0; it < my_tiles; ++it) {
         const int tile = blockIdx.x + it * gridDim.x;
@@ -1043,11 +1049,110 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         };
         const int k_dma = nrounds >= 3 * kWaves ? 2 : 1;
         int k = 0, next = 0;
+        // a round's lane base inside the halo buffer: row (lz, lx), this lane's dword, plus the lane group's planes
+        auto round_base = [&](int round) -> const uint8_t* {
+            const int lz = round >> hx_shift, lx = (round & (half_tx - 1)) * 2;
+            return hb + ((lz * kXP + lx) * DW + n + D0) * 4;
+        };
+        // raw dwords of unit (slot, x-row h): halo row h1 in r[0..2], h2 in r[3..5] (dwords D0 D1 D2)
+        auto load_unit = [&](const uint8_t* xb, auto SLOT, auto HC, uint32_t (&r)[6]) {
+            constexpr int slot = decltype(SLOT)::value, h = decltype(HC)::value;
+            constexpr bool single = fold_slot_single(slot / kFoldRows, slot % kFoldRows);
+            const uint8_t *p1, *p2;
+            if constexpr (fold_slot_irregular(slot)) {
+                p1 = xb + (slot == 8 ? ir8 : ir11a) + h * (DW * 4);
+                p2 = xb + ir11b + h * (DW * 4);
+            } else {
+                constexpr int c1 = (fold_slot_a(slot) * kXP + fold_slot_dx(slot)) * (DW * 4) + h * (DW * 4);
+                constexpr int c2 = (fold_slot_a(slot) * kXP + 8 - fold_slot_dx(slot)) * (DW * 4) + h * (DW * 4);
+                p1 = xb + qbase + c1;   // (xb + qbase is one add per round; c1, c2 are immediates of the reads)
+                p2 = xb + qbase + c2;
+            }
+            const uint32_t* d1 = reinterpret_cast<const uint32_t*>(p1);
+            r[0] = d1[0]; r[1] = d1[1]; r[2] = d1[2];
+            if constexpr (!single) {
+                const uint32_t* d2 = reinterpret_cast<const uint32_t*>(p2);
+                r[3] = d2[0]; r[4] = d2[1]; r[5] = d2[2];
+            }
+        };
+        // fold one unit into component J of the four residues' operand quads X[r] (a step's B operand for tile (h, r) is the
+        // quad (row 0, row 1, row 2, centres): written in place, component by component); also returns the summed dword 1,
+        // whose byte r is the centre tap of residue r
+        auto fold_unit = [&](const uint32_t (&r)[6], auto SLOT, i32x4 (&X)[4], uint32_t& centre) {
+            constexpr int slot = decltype(SLOT)::value, J = slot % kFoldRows;
+            constexpr bool single = fold_slot_single(slot / kFoldRows, J);
+            const uint32_t R0 = single ? r[0] : r[0] + r[3];
+            const uint32_t R1 = single ? r[1] : r[1] + r[4];
+            const uint32_t R2 = single ? r[2] : r[2] + r[5];
+            X[0][J] = (int)(R0 + __builtin_amdgcn_perm(R2, R1, 0x01020304u));
+            X[1][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 1) + __builtin_amdgcn_perm(R2, R1, 0x02030405u));
+            X[2][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 2) + __builtin_amdgcn_perm(R2, R1, 0x03040506u));
+            X[3][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 3) + __builtin_amdgcn_perm(R2, R1, 0x04050607u));
+            centre = R1;
+        };
+        auto centres = [&](uint32_t c0, uint32_t c1, uint32_t c2, i32x4 (&X)[4]) {
+            uint32_t o[4];
+            transpose4(c0, c1, c2, 0u, o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[r][3] = (int)o[r];
+        };
+        constexpr std::integral_constant<int, 0> H0{};
+        constexpr std::integral_constant<int, 1> H1{};
+        // operands of step ST at lane base xb, un-pipelined (a tile's first round)
+        auto build_step = [&](const uint8_t* xb, auto ST, i32x4 (&X)[2][4]) {
+            constexpr int st = decltype(ST)::value;
+            constexpr std::integral_constant<int, st * kFoldRows + 0> L0{};
+            constexpr std::integral_constant<int, st * kFoldRows + 1> L1{};
+            constexpr std::integral_constant<int, st * kFoldRows + 2> L2{};
+            uint32_t c00, c01, c10, c11, c20, c21;
+            uint32_t r00[6], r01[6], r10[6], r11[6], r20[6], r21[6];
+            load_unit(xb, L0, H0, r00); load_unit(xb, L0, H1, r01);
+            load_unit(xb, L1, H0, r10); load_unit(xb, L1, H1, r11);
+            load_unit(xb, L2, H0, r20); load_unit(xb, L2, H1, r21);
+            fold_unit(r00, L0, X[0], c00); fold_unit(r01, L0, X[1], c01);
+            fold_unit(r10, L1, X[0], c10); fold_unit(r11, L1, X[1], c11);
+            fold_unit(r20, L2, X[0], c20); fold_unit(r21, L2, X[1], c21);
+            centres(c00, c10, c20, X[0]);
+            centres(c01, c11, c21, X[1]);
+        };
+        // The next step's operands are built in eight pieces behind the eight MFMA groups of the current step: pieces 0..5
+        // fold unit u = (j, h) = (piece >> 1, piece & 1), pieces 6, 7 transpose the centres of x-row 0, 1.  The raw dwords of
+        // unit u are requested two pieces ahead: units 0, 1 during pieces 6, 7 of the step BEFORE (pipe_open for the first).
+        uint32_t praw[6][6], pcen[3][2];
+        auto pipe_load = [&](const uint8_t* xb, auto ST, auto UC) {
+            constexpr int st = decltype(ST)::value, u = decltype(UC)::value;
+            load_unit(xb, std::integral_constant<int, st * kFoldRows + (u >> 1)>{}, std::integral_constant<int, (u & 1)>{}, praw[u]);
+        };
+        auto pipe_open = [&](const uint8_t* xb, auto ST) {
+            pipe_load(xb, ST, std::integral_constant<int, 0>{});
+            pipe_load(xb, ST, std::integral_constant<int, 1>{});
+        };
+        // piece PC of building step ST (lane base xb) into X; pieces 6, 7 also request units 0, 1 of step NST at base nxb
+        // (NST = -1: nothing follows)
+        auto pipe_piece = [&](const uint8_t* xb, auto ST, auto PC, i32x4 (&X)[2][4], const uint8_t* nxb, auto NST) {
+            constexpr int st = decltype(ST)::value, piece = decltype(PC)::value, nst = decltype(NST)::value;
+            if constexpr (piece + 2 < 6) pipe_load(xb, ST, std::integral_constant<int, piece + 2>{});
+            if constexpr (piece < 6) {
+                constexpr int j = piece >> 1, h = piece & 1;
+                fold_unit(praw[piece], std::integral_constant<int, st * kFoldRows + j>{}, X[h], pcen[j][h]);
+            } else {
+                constexpr int h = piece - 6;
+                centres(pcen[0][h], pcen[1][h], pcen[2][h], X[h]);
+                if constexpr (nst >= 0) pipe_load(nxb, std::integral_constant<int, (nst < 0 ? 0 : nst)>{}, std::integral_constant<int, h>{});
+            }
+        };
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
+        constexpr std::integral_constant<int, 2> S2{};
+        constexpr std::integral_constant<int, 3> S3{};
+        constexpr std::integral_constant<int, -1> SNone{};
+        i32x4 Xa[2][4], Xb[2][4];   // operand quads [h][r] of the current / the next step
+        bool have_first = false;    // Xa holds this round's step-0 operands (built behind the previous round's last step)
         for (int round = claim(); round < nrounds; round = next, ++k) {
             next = claim();
             if (k == k_dma && dma_pending) dma_ahead();
             const int lz = round >> hx_shift, lx = (round & (half_tx - 1)) * 2;
-            const uint8_t* xb = hb + ((lz * s.XP + lx) * DW + n + D0) * 4;
+            const uint8_t* xb = round_base(round);
 
             i32x4 acc[3][NV];
             auto load_w = [&](int st, i32x4 (&w)[3]) {
@@ -1062,59 +1167,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
                 for (int d = 0; d < 3; ++d)
                     acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv, first ? i32x4{0, 0, 0, 0} : acc[d][v], 0, 0, 0);
             };
-            // raw dwords of one (row j, x-row h) unit: halo row h1 in r[0..2], h2 in r[3..5] (dwords D0 D1 D2)
-            auto load_unit = [&](int off1, int off2, int h, bool single, uint32_t (&r)[6]) {
-                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(xb + off1 + h * (DW * 4));
-                r[0] = p1[0]; r[1] = p1[1]; r[2] = p1[2];
-                if (!single) {
-                    const uint32_t* p2 = reinterpret_cast<const uint32_t*>(xb + off2 + h * (DW * 4));
-                    r[3] = p2[0]; r[4] = p2[1]; r[5] = p2[2];
-                }
-            };
-            // fold one unit into component J of the four residues' operand quads X[r] (a step's B operand for tile (h, r) is
-            // the quad (row 0, row 1, row 2, centres): written in place, component by component); also returns the summed
-            // dword 1, whose byte r is the centre tap of residue r
-            auto fold_unit = [&](const uint32_t (&r)[6], bool single, auto JC, i32x4 (&X)[4], uint32_t& centre) {
-                constexpr int J = decltype(JC)::value;
-                const uint32_t R0 = single ? r[0] : r[0] + r[3];
-                const uint32_t R1 = single ? r[1] : r[1] + r[4];
-                const uint32_t R2 = single ? r[2] : r[2] + r[5];
-                X[0][J] = (int)(R0 + __builtin_amdgcn_perm(R2, R1, 0x01020304u));
-                X[1][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 1) + __builtin_amdgcn_perm(R2, R1, 0x02030405u));
-                X[2][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 2) + __builtin_amdgcn_perm(R2, R1, 0x03040506u));
-                X[3][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 3) + __builtin_amdgcn_perm(R2, R1, 0x04050607u));
-                centre = R1;
-            };
-            auto centres = [&](uint32_t c0, uint32_t c1, uint32_t c2, i32x4 (&X)[4]) {
-                uint32_t o[4];
-                transpose4(c0, c1, c2, 0u, o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[r][3] = (int)o[r];
-            };
-            constexpr std::integral_constant<int, 0> J0{};
-            constexpr std::integral_constant<int, 1> J1{};
-            constexpr std::integral_constant<int, 2> J2{};
-            // operands of one step: X[h][r], un-pipelined form (a round's first step)
-            auto build_step = [&](auto ST, i32x4 (&X)[2][4]) {
-                constexpr int st = decltype(ST)::value;
-                const int4 o01 = foff[(st * 4 + q) * 2], o2 = foff[(st * 4 + q) * 2 + 1];
-                uint32_t c00, c01, c10, c11, c20, c21;
-                uint32_t r00[6], r01[6], r10[6], r11[6], r20[6], r21[6];
-                load_unit(o01.x, o01.y, 0, fold_slot_single(st, 0), r00);
-                load_unit(o01.x, o01.y, 1, fold_slot_single(st, 0), r01);
-                load_unit(o01.z, o01.w, 0, fold_slot_single(st, 1), r10);
-                load_unit(o01.z, o01.w, 1, fold_slot_single(st, 1), r11);
-                load_unit(o2.x, o2.y, 0, fold_slot_single(st, 2), r20);
-                load_unit(o2.x, o2.y, 1, fold_slot_single(st, 2), r21);
-                fold_unit(r00, fold_slot_single(st, 0), J0, X[0], c00);
-                fold_unit(r01, fold_slot_single(st, 0), J0, X[1], c01);
-                fold_unit(r10, fold_slot_single(st, 1), J1, X[0], c10);
-                fold_unit(r11, fold_slot_single(st, 1), J1, X[1], c11);
-                fold_unit(r20, fold_slot_single(st, 2), J2, X[0], c20);
-                fold_unit(r21, fold_slot_single(st, 2), J2, X[1], c21);
-                centres(c00, c10, c20, X[0]);
-                centres(c01, c11, c21, X[1]);
-            };
             auto mma_step = [&](const i32x4 (&w)[3], const i32x4 (&X)[2][4], bool first, auto&& work) {
                 auto group = [&](auto VC) {   // (compile-time v: the pieces index registers, never memory)
                     constexpr int v = decltype(VC)::value, h = v >> 2, r = v & 3;
@@ -1128,54 +1180,33 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
                 group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
                 group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
             };
-            // the next step's operands, built in eight pieces behind the eight MFMA groups of the current step: pieces
-            // 0..5 fold unit (j, h) = (piece >> 1, piece & 1) whose raw dwords were requested two pieces earlier, pieces 6, 7
-            // transpose the centres of x-row 0, 1
-            uint32_t praw[6][6], pcen[3][2];
-            int4 po01, po2;
-            auto pipe_open = [&](auto ST) {   // offsets and the first two units' raw dwords
-                constexpr int st = decltype(ST)::value;
-                po01 = foff[(st * 4 + q) * 2];
-                po2 = foff[(st * 4 + q) * 2 + 1];
-                load_unit(po01.x, po01.y, 0, fold_slot_single(st, 0), praw[0]);
-                load_unit(po01.x, po01.y, 1, fold_slot_single(st, 0), praw[1]);
-            };
-            auto pipe_piece = [&](auto ST, auto PC, i32x4 (&X)[2][4]) {
-                constexpr int st = decltype(ST)::value, piece = decltype(PC)::value;
-                if constexpr (piece + 2 < 6) {
-                    constexpr int u = piece + 2, j = u >> 1, h = u & 1;
-                    load_unit(j == 1 ? po01.z : po2.x, j == 1 ? po01.w : po2.y, h, fold_slot_single(st, j), praw[u]);
-                }
-                if constexpr (piece < 6) {
-                    constexpr int j = piece >> 1, h = piece & 1;
-                    fold_unit(praw[piece], fold_slot_single(st, j), std::integral_constant<int, j>{}, X[h], pcen[j][h]);
-                } else {
-                    constexpr int h = piece - 6;
-                    centres(pcen[0][h], pcen[1][h], pcen[2][h], X[h]);
-                }
-            };
-            constexpr std::integral_constant<int, 0> S0{};
-            constexpr std::integral_constant<int, 1> S1{};
-            constexpr std::integral_constant<int, 2> S2{};
-            constexpr std::integral_constant<int, 3> S3{};
             i32x4 wa[3], wb[3];
-            i32x4 Xa[2][4], Xb[2][4];
             load_w(0, wa);
-            build_step(S0, Xa);
+            if (!have_first) build_step(xb, S0, Xa);
+            pipe_open(xb, S1);   // (not carried over from the previous round: twelve registers less across the epilogue)
             load_w(1, wb);
-            pipe_open(S1);
             __builtin_amdgcn_sched_barrier(0);
-            mma_step(wa, Xa, true, [&](auto v) { pipe_piece(S1, v, Xb); });
+            mma_step(wa, Xa, true, [&](auto v) { pipe_piece(xb, S1, v, Xb, xb, S2); });
             load_w(2, wa);
-            pipe_open(S2);
             __builtin_amdgcn_sched_barrier(0);
-            mma_step(wb, Xb, false, [&](auto v) { pipe_piece(S2, v, Xa); });
+            mma_step(wb, Xb, false, [&](auto v) { pipe_piece(xb, S2, v, Xa, xb, S3); });
             load_w(3, wb);
-            pipe_open(S3);
             __builtin_amdgcn_sched_barrier(0);
-            mma_step(wa, Xa, false, [&](auto v) { pipe_piece(S3, v, Xb); });
+            // the last step carries step 0 of this wave's NEXT round of the tile.  No branch: without a next round the same
+            // work runs on this round's rows and is dropped (a second copy of the two steps cost more in registers than
+            // the wasted folds of a tile's last round cost in time)
+#ifdef SN_I8F_CARRY   // step 0 of the wave's next round built behind the last step: [measured] slower (0.142 vs 0.132 ms) -- the
+                      // carried operands spill around the epilogue and a tile's last round folds for nothing
+            have_first = next < nrounds;
+            const uint8_t* nxb = have_first ? round_base(next) : xb;
+            mma_step(wa, Xa, false, [&](auto v) { pipe_piece(xb, S3, v, Xb, nxb, S0); });
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(wb, Xb, false, [&](auto v) { pipe_piece(nxb, S0, v, Xa, nxb, SNone); });
+#else
+            mma_step(wa, Xa, false, [&](auto v) { pipe_piece(xb, S3, v, Xb, xb, SNone); });
             __builtin_amdgcn_sched_barrier(0);
             mma_step(wb, Xb, false, [](auto) {});
+#endif
             finish_round<OT>(s, c, lz, lx, n, q, acc, scale, lamsc, lamhi, act, out, V);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1192,7 +1223,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
 size_t lds_bytes_fold(const Shape& s) {
     const size_t hdw = (size_t)s.ZP * s.XP * DW;
     const size_t ring = kNB * hdw * 4, alias = 2 * hdw * 4 + ((size_t)s.G * 729 + 1) * sizeof(float);
-    return (size_t)kFoldSteps * 3 * 64 * 16 + (size_t)kFoldSteps * 4 * 2 * 16 + 64 + 64 + 128 + 128 + 64 + sizeof(FoldPlan) +
+    return (size_t)kFoldSteps * 3 * 64 * 16 + 64 + 64 + 128 + 128 + 64 + sizeof(FoldPlan) +
            (ring > alias ? ring : alias) + 16;
 }
 
@@ -1200,21 +1231,18 @@ size_t lds_bytes_fold(const Shape& s) {
 // LDS cycle each: at every slot their halo rows differ by 2 (mod 4) -- dz and dz + 2 at the same dx', or dx' and dx' + 2
 // at dz = 8 -- which is 16 banks with 24-dword rows, for h1 and for h2 alike.
 void plan_fold(int XP, FoldPlan& p) {
-    static const int dpos[9] = {0, 1, 3, 4, 6, 7, 9, 10, 11};   // double slots (st * 3 + j), in the order they are filled
-    static const int spos[3] = {2, 5, 8};                        // single slots
     for (int qq = 0; qq < 4; ++qq) {
         auto put = [&](int slot, int dz, int dxp, bool pad) {
             p.h1[qq][slot] = (short)(dz * XP + dxp);
             p.h2[qq][slot] = (short)(dz * XP + 8 - dxp);
             p.tap[qq][slot] = pad ? (short)-1 : (short)(dz * 9 + dxp);
         };
-        for (int i = 0; i < 8; ++i) put(dpos[i], 2 * qq + (i >> 2), i & 3, false);   // dz in {2q, 2q + 1}, dx' = 0..3
+        for (int slot = 0; slot < kFoldSlots; ++slot)   // the regular slots: the closed form the kernel's immediates use
+            if (!fold_slot_irregular(slot)) put(slot, 2 * qq + fold_slot_a(slot), fold_slot_dx(slot), false);
         static const int last_dx[4] = {0, 2, 1, 3};
-        put(dpos[8], 8, last_dx[qq], false);
-        put(spos[0], 2 * qq, 4, false);        // (0,4) (2,4) (4,4) (6,4)
-        put(spos[1], 2 * qq + 1, 4, false);    // (1,4) (3,4) (5,4) (7,4)
+        put(11, 8, last_dx[qq], false);        // plane 8's doubles: dx' and dx' + 2 for the lane groups of one LDS cycle
         static const int pad_dz[4] = {8, 6, 0, 2};
-        put(spos[2], pad_dz[qq], 4, qq != 0);  // (8,4), then pads on rows 2 (mod 4) apart pairwise
+        put(8, pad_dz[qq], 4, qq != 0);        // (8, 4), then pads on rows 2 (mod 4) apart pairwise
     }
 }
 
@@ -1344,17 +1372,24 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
         plan_fold(sf.XP, sf.fplan);
         sf.route = flag;
         const size_t ldsf = lds_bytes_fold(sf);
-        if (ldsf <= (size_t)kMaxLds) {
-#define SN_LAUNCH_I8F(OT)                                                                                        \
+        if (ldsf <= (size_t)kMaxLds && (sf.XP == 17 || sf.XP == 13 || sf.XP == 11)) {
+#define SN_LAUNCH_I8F(OT, XPV)                                                                                   \
     do {                                                                                                         \
-        auto kern = conv_occ_i8f_kernel<OT>;                                                                     \
+        auto kern = conv_occ_i8f_kernel<OT, XPV>;                                                                \
         if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
             return check_launch("sn_conv_bank(i8f: hipFuncSetAttribute)");                                       \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), ldsf, stream, x, bank, lambdas, sf, (OT*)act,       \
                            (OT*)out);                                                                            \
     } while (0)
-            if (out_dtype == SN_F32) SN_LAUNCH_I8F(float);
-            else SN_LAUNCH_I8F(double);
+#define SN_LAUNCH_I8F_XP(XPV)                                                                                    \
+    do {                                                                                                         \
+        if (out_dtype == SN_F32) SN_LAUNCH_I8F(float, XPV);                                                      \
+        else SN_LAUNCH_I8F(double, XPV);                                                                         \
+    } while (0)
+            if (sf.XP == 17) SN_LAUNCH_I8F_XP(17);        // TX = 8
+            else if (sf.XP == 13) SN_LAUNCH_I8F_XP(13);   // TX = 4
+            else SN_LAUNCH_I8F_XP(11);                    // TX = 2
+#undef SN_LAUNCH_I8F_XP
 #undef SN_LAUNCH_I8F
             if (int rc = check_launch("sn_conv_bank(i8f)")) return rc;
             folded = true;

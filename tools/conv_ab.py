@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two forms of K3' (stride-4 kernel vs four-copy kernel) and of the guard's gated fp32 launch, interleaved
+"""A/B of the three forms of K3' (folded kernel vs stride-4 kernel vs four-copy kernel) and of the guard's gated fp32 launch, interleaved
 rounds in ONE process on the bench's C2 batch (cdna_hip_programming.md rule 24).
     python tools/conv_ab.py [--rounds 5] [--iters 40] [--batch 32] [--grid 64]"""
 import argparse
@@ -44,10 +44,12 @@ def main():
             _hip.conv_bank(occ, bank, lam, want_act=False, want_out=True)
 
     variants = {
-        "stride4+guard": dict(legacy=0, tol=90000),
-        "stride4 noguard": dict(legacy=0, tol=0),
-        "legacy+guard": dict(legacy=1, tol=90000),
-        "legacy noguard": dict(legacy=1, tol=0),
+        "folded+guard": dict(legacy=0, tol=90000, fold=1),
+        "folded noguard": dict(legacy=0, tol=0, fold=1),
+        "stride4+guard": dict(legacy=0, tol=90000, fold=0),
+        "stride4 noguard": dict(legacy=0, tol=0, fold=0),
+        "legacy+guard": dict(legacy=1, tol=90000, fold=0),
+        "legacy noguard": dict(legacy=1, tol=0, fold=0),
     }
     for k, v in os.environ.items():
         if k.startswith("SN_CONV"):
@@ -61,6 +63,7 @@ def main():
         for name, v in variants.items():
             _hip.set_option("conv_i8_legacy", v["legacy"])
             _hip.set_option("conv_i8_tolerance_ppb", v["tol"])
+            _hip.set_option("conv_i8_fold", v["fold"])
             run(5)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,6 +74,7 @@ def main():
             res[name].append(e0.elapsed_time(e1) / args.iters)
     _hip.set_option("conv_i8_legacy", 0)
     _hip.set_option("conv_i8_tolerance_ppb", 90000)
+    _hip.set_option("conv_i8_fold", 1)
     flops = 2.0 * args.grid ** 3 * 729 * 16 * args.batch
     for name, ts in res.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
