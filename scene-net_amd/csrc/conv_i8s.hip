@@ -921,6 +921,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     constexpr int ntaps = 729;
+    SN_ST(0);
     const int hrows = s.ZP * s.XP;
     const int hdw = hrows * DW;
     // LDS carve-up
@@ -945,16 +946,22 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
     const short* plan_tap = plan_s + 2 * 4 * kFoldSlots;
     stage_bank_and_first_halos(s, bank, ntaps, bank_s, hbuf, hdw, x, my_tiles, tid, wave, lane);
     lds_barrier();
+    SN_ST(1);
     // ---- is every kernel symmetric in x and in y?  (bitwise on the fp32 weights; a NaN pattern compares like any other)
-    {
+    {   // one (kernel, dz, dx <= 4) row of nine weights per item: against its mirror row 8 - dx, and against its own reverse
         bool asym = false;
         const uint32_t* wb = reinterpret_cast<const uint32_t*>(bank_s);
-        for (int i = tid; i < s.G * ntaps; i += kThreads) {
-            const int t = i % ntaps, g = i / ntaps;
-            const int dy = t % 9, dx = (t / 9) % 9, dz = t / 81;
-            const uint32_t w = wb[i];
-            asym |= w != wb[g * ntaps + (dz * 9 + (8 - dx)) * 9 + dy];
-            asym |= w != wb[g * ntaps + (dz * 9 + dx) * 9 + (8 - dy)];
+        for (int i = tid; i < s.G * 9 * 5; i += kThreads) {
+            const int dx = i % 5, pl = i / 5;           // pl = g * 9 + dz
+            const uint32_t* ra = wb + (pl * 9 + dx) * 9;
+            const uint32_t* rb = wb + (pl * 9 + 8 - dx) * 9;
+            uint32_t a[9], b[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { a[k] = ra[k]; b[k] = rb[k]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) asym |= a[k] != b[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asym |= (a[k] != a[8 - k]) | (b[k] != b[8 - k]);
         }
         if (asym) flags[2] = 1;   // benign race: every writer stores 1
     }
@@ -965,8 +972,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
         return;
     }
+    SN_ST(6);   // (symmetry checked)
     quantise_kernels(s, ntaps, bank_s, scale, bnd, wave, lane);
     lds_barrier();
+    SN_ST(2);
     {
         const bool exceeded = bound_exceeded<OT>(s, bnd, lambdas, act, out);
         if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
@@ -1005,6 +1014,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         Wd[(st * 3 + 1) * 64 + l] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
         Wd[(st * 3 + 2) * 64 + l] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
     }
+    SN_ST(3);
     if (tid < 16) {
         const float ls = (out && tid < s.G) ? lambdas[tid] * scale[tid] : 0.0f;
         lamsc[tid] = ls;
@@ -1016,6 +1026,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    SN_ST(4);
 
     const int half_tx = s.TX >> 1;
     const int hx_shift = 31 - __builtin_clz(half_tx);
@@ -1218,6 +1229,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         }
     }
     if (!healthy && lane == 0) flags[1] = 1;
+    SN_ST(5);
 }
 
 size_t lds_bytes_fold(const Shape& s) {

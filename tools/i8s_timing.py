@@ -34,6 +34,8 @@ def show(name, a):
 print("workgroups", n)
 show("start", us(t[:, 0] - t0))
 show("bank staged", us(t[:, 1] - t[:, 0]))
+if (t[:, 6] > 0).all():   # the folded kernel stamps the end of its symmetry check
+    show("symmetry check (folded kernel)", us(t[:, 6] - t[:, 1]))
 show("scales + bounds", us(t[:, 2] - t[:, 1]))
 show("tables", us(t[:, 3] - t[:, 2]))
 show("first halos in + barrier", us(t[:, 4] - t[:, 3]))
