@@ -75,6 +75,9 @@ struct RowPlan {
 // kFoldSteps MFMA steps of kFoldRows folded rows per lane group; slot (st, j) is SINGLE (dx' = 4: one halo row) for j = 2 of
 // steps 0..2 and DOUBLE (dx' < 4: halo rows dx' and 8 - dx' summed) elsewhere -- the same for all four lane groups, so the
 // step code has no per-lane case.
+#ifndef SN_I8F_AHEAD
+#define SN_I8F_AHEAD 2
+#endif
 constexpr int kFoldSteps = 4, kFoldRows = 3, kFoldSlots = kFoldSteps * kFoldRows;
 constexpr bool fold_slot_single(int st, int j) { return j == 2 && st < 3; }
 struct FoldPlan {
@@ -1095,10 +1098,14 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             const uint32_t R0 = single ? r[0] : r[0] + r[3];
             const uint32_t R1 = single ? r[1] : r[1] + r[4];
             const uint32_t R2 = single ? r[2] : r[2] + r[5];
+#ifdef SN_I8F_NOFOLD   // timing experiment (wrong results): the round without the y fold
+            X[0][J] = (int)R0; X[1][J] = (int)R1; X[2][J] = (int)R2; X[3][J] = (int)R0;
+#else
             X[0][J] = (int)(R0 + __builtin_amdgcn_perm(R2, R1, 0x01020304u));
             X[1][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 1) + __builtin_amdgcn_perm(R2, R1, 0x02030405u));
             X[2][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 2) + __builtin_amdgcn_perm(R2, R1, 0x03040506u));
             X[3][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 3) + __builtin_amdgcn_perm(R2, R1, 0x04050607u));
+#endif
             centre = R1;
         };
         auto centres = [&](uint32_t c0, uint32_t c1, uint32_t c2, i32x4 (&X)[4]) {
@@ -1134,23 +1141,26 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             constexpr int st = decltype(ST)::value, u = decltype(UC)::value;
             load_unit(xb, std::integral_constant<int, st * kFoldRows + (u >> 1)>{}, std::integral_constant<int, (u & 1)>{}, praw[u]);
         };
+        constexpr int kAhead = SN_I8F_AHEAD;   // raw dwords are requested this many pieces before they are folded
         auto pipe_open = [&](const uint8_t* xb, auto ST) {
             pipe_load(xb, ST, std::integral_constant<int, 0>{});
             pipe_load(xb, ST, std::integral_constant<int, 1>{});
+            if constexpr (kAhead >= 3) pipe_load(xb, ST, std::integral_constant<int, 2>{});
         };
         // piece PC of building step ST (lane base xb) into X; pieces 6, 7 also request units 0, 1 of step NST at base nxb
         // (NST = -1: nothing follows)
         auto pipe_piece = [&](const uint8_t* xb, auto ST, auto PC, i32x4 (&X)[2][4], const uint8_t* nxb, auto NST) {
             constexpr int st = decltype(ST)::value, piece = decltype(PC)::value, nst = decltype(NST)::value;
-            if constexpr (piece + 2 < 6) pipe_load(xb, ST, std::integral_constant<int, piece + 2>{});
             if constexpr (piece < 6) {
                 constexpr int j = piece >> 1, h = piece & 1;
                 fold_unit(praw[piece], std::integral_constant<int, st * kFoldRows + j>{}, X[h], pcen[j][h]);
             } else {
                 constexpr int h = piece - 6;
                 centres(pcen[0][h], pcen[1][h], pcen[2][h], X[h]);
-                if constexpr (nst >= 0) pipe_load(nxb, std::integral_constant<int, (nst < 0 ? 0 : nst)>{}, std::integral_constant<int, h>{});
             }
+            if constexpr (piece + kAhead < 6) pipe_load(xb, ST, std::integral_constant<int, piece + kAhead>{});
+            else if constexpr (piece >= 8 - kAhead && nst >= 0)
+                pipe_load(nxb, std::integral_constant<int, (nst < 0 ? 0 : nst)>{}, std::integral_constant<int, piece - (8 - kAhead)>{});
         };
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, 1> S1{};
@@ -1176,7 +1186,11 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             auto mma_tile = [&](const i32x4 (&w)[3], const i32x4& xv, int v, bool first) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
+#ifdef SN_I8F_NOMMA   // timing experiment (wrong results): the round without its MFMAs
+                    acc[d][v] = first ? (w[d] ^ xv) : (acc[d][v] ^ xv);
+#else
                     acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv, first ? i32x4{0, 0, 0, 0} : acc[d][v], 0, 0, 0);
+#endif
             };
             auto mma_step = [&](const i32x4 (&w)[3], const i32x4 (&X)[2][4], bool first, auto&& work) {
                 auto group = [&](auto VC) {   // (compile-time v: the pieces index registers, never memory)
