@@ -1168,7 +1168,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         constexpr std::integral_constant<int, 3> S3{};
         constexpr std::integral_constant<int, -1> SNone{};
         i32x4 Xa[2][4], Xb[2][4];   // operand quads [h][r] of the current / the next step
-        bool have_first = false;    // Xa holds this round's step-0 operands (built behind the previous round's last step)
         for (int round = claim(); round < nrounds; round = next, ++k) {
             next = claim();
             if (k == k_dma && dma_pending) dma_ahead();
@@ -1207,7 +1206,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             };
             i32x4 wa[3], wb[3];
             load_w(0, wa);
-            if (!have_first) build_step(xb, S0, Xa);
+            build_step(xb, S0, Xa);
             pipe_open(xb, S1);   // (not carried over from the previous round: twelve registers less across the epilogue)
             load_w(1, wb);
             __builtin_amdgcn_sched_barrier(0);
@@ -1220,18 +1219,11 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             // the last step carries step 0 of this wave's NEXT round of the tile.  No branch: without a next round the same
             // work runs on this round's rows and is dropped (a second copy of the two steps cost more in registers than
             // the wasted folds of a tile's last round cost in time)
-#ifdef SN_I8F_CARRY   // step 0 of the wave's next round built behind the last step: [measured] slower (0.142 vs 0.132 ms) -- the
-                      // carried operands spill around the epilogue and a tile's last round folds for nothing
-            have_first = next < nrounds;
-            const uint8_t* nxb = have_first ? round_base(next) : xb;
-            mma_step(wa, Xa, false, [&](auto v) { pipe_piece(xb, S3, v, Xb, nxb, S0); });
-            __builtin_amdgcn_sched_barrier(0);
-            mma_step(wb, Xb, false, [&](auto v) { pipe_piece(nxb, S0, v, Xa, nxb, SNone); });
-#else
+            // (carrying step 0 of the wave's next round across the epilogue was tried: slower, 0.142 vs 0.132 ms -- the carried
+            // operands spill around the epilogue and a tile's last round folds for nothing)
             mma_step(wa, Xa, false, [&](auto v) { pipe_piece(xb, S3, v, Xb, xb, SNone); });
             __builtin_amdgcn_sched_barrier(0);
             mma_step(wb, Xb, false, [](auto) {});
-#endif
             finish_round<OT>(s, c, lz, lx, n, q, acc, scale, lamsc, lamhi, act, out, V);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
