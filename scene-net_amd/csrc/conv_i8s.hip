@@ -444,10 +444,9 @@ __device__ unsigned long long g_i8s_w[1024 * 8 * 8];   // [workgroup][wave][phas
 // run-time form hipcc keeps a second copy of the 96 accumulator registers across the join and spills); kNT < 0: taken
 // from the shape.
 template <typename OT, int kNP, int kNT, int kODD>
-__global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* __restrict__ x,
-                                                                const float* __restrict__ bank,
-                                                                const float* __restrict__ lambdas, Shape s,
-                                                                OT* __restrict__ act, OT* __restrict__ out) {
+__device__ __forceinline__ void conv_occ_i8s_body(const uint8_t* __restrict__ x, const float* __restrict__ bank,
+                                                  const float* __restrict__ lambdas, const Shape& s,
+                                                  OT* __restrict__ act, OT* __restrict__ out) {
     if (!s.gate.pass()) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
@@ -889,6 +888,15 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
     SN_ST(5);
 }
 
+// the stride-4 kernel as a launch of its own (banks the folded kernel is not tried on)
+template <typename OT, int kNP, int kNT, int kODD>
+__global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* __restrict__ x,
+                                                                const float* __restrict__ bank,
+                                                                const float* __restrict__ lambdas, Shape s,
+                                                                OT* __restrict__ act, OT* __restrict__ out) {
+    conv_occ_i8s_body<OT, kNP, kNT, kODD>(x, bank, lambdas, s, act, out);
+}
+
 // ================================================================================================ folded kernel
 // GENEO kernels are radial in (x, y) (cylinder.py:152-176, arrow.py:214-252, neg_sphere.py:166-199): W[dz][dx][dy] =
 // W[dz][8-dx][dy] = W[dz][dx][8-dy], bit for bit (the generators evaluate the same expression on (dx-4)^2 + (dy-4)^2).
@@ -902,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 // transpose the stride-4 kernel uses for tap 8.  A step = 3 folded rows + their centre dword per lane group; 45 folded rows
 // (+ 3 pads) over 4 lane groups x 12 slots.  Everything else -- halo ring, LDS-DMA, claimed rounds, quantisation, guard,
 // epilogue -- is the stride-4 kernel's.  The prologue CHECKS the symmetry on the fp32 weights (bitwise); a bank that is not
-// symmetric is not served here: *route = 2 sends the launch to the stride-4 kernel enqueued behind this one.
+// symmetric takes the stride-4 kernel's body instead, in the same launch.
 // Compile-time halo pitch kXP (17 / 13 / 11 for TX = 8 / 4 / 2): the halo byte offset of a regular slot is
 //     q * (2 kXP 96) + (a kXP + dx') 96        (lane group q carries planes dz = 2 q + a, a = 0, 1),
 // one per-lane register plus an immediate of the LDS read -- no offset table, no address arithmetic in the rounds.  The two
@@ -970,9 +978,13 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
     }
     lds_barrier();
     if (flags[2]) {
-        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = 2;
+        // not symmetric: the stride-4 kernel's whole job, in this launch (a second, gated launch cost 2.8 us per call
+        // even when it had nothing to do).  Its body starts from scratch -- own LDS layout, own prologue, and it writes the
+        // route flag (0 / 1) itself; the halos requested above must have landed before their LDS is reused.
         if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_fold_counts[1], 1ull);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        conv_occ_i8s_body<OT, 10, 6, 1>(x, bank, lambdas, s, act, out);
         return;
     }
     SN_ST(6);   // (symmetry checked)
@@ -1378,8 +1390,8 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     // quantisation guard (see the header): tolerance on the worst-case activation error of the int8 path
     s.tol = sn::option_conv_i8_tolerance();
     const int grid = cus < s.ntiles ? cus : s.ntiles;
-    // 1. the folded kernel (banks symmetric in x and y: every GENEO bank) -- it checks the symmetry on the device and leaves
-    //    *flag = 0 (served), 1 (bound exceeded: fp32 kernel) or 2 (not symmetric: the stride-4 kernel below)
+    // 1. the folded kernel (banks symmetric in x and y: every GENEO bank) -- it checks the symmetry on the device, runs the
+    //    stride-4 body itself for a bank that is not, and leaves *flag = 0 (served) or 1 (bound exceeded: fp32 kernel)
     const char* nofold = getenv("SN_CONV_I8_NOFOLD");
     int32_t* flag = sn::device_flag_slot();
     const bool fold = kz == 9 && kx == 9 && flag && !(nofold && nofold[0] == '1') && sn::option_conv_i8_fold() &&
@@ -1389,7 +1401,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
         Shape sf = s;
         plan_fold(sf.XP, sf.fplan);
         sf.route = flag;
-        const size_t ldsf = lds_bytes_fold(sf);
+        const size_t ldsf = lds_bytes_fold(sf) > lds_bytes(s) ? lds_bytes_fold(sf) : lds_bytes(s);   // (it may run the stride-4 body)
         if (ldsf <= (size_t)kMaxLds && (sf.XP == 17 || sf.XP == 13 || sf.XP == 11)) {
 #define SN_LAUNCH_I8F(OT, XPV)                                                                                   \
     do {                                                                                                         \
@@ -1413,15 +1425,14 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
             folded = true;
         }
     }
-    // 2. the stride-4 kernel: the whole job without the folded kernel, else only what it declined (*flag == 2)
+    // 2. the stride-4 kernel as its own launch, when the folded kernel was not tried (it runs the stride-4 body itself for
+    //    a bank it declines)
     s.route = folded ? flag : nullptr;
-    if (!folded && s.tol > 0.0f) {
-        s.route = flag;
-        if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
-    }
-    {
-        sn::GateScope declined(folded ? flag : nullptr, 2);
-        s.gate = sn::current_gate();
+    if (!folded) {
+        if (s.tol > 0.0f) {
+            s.route = flag;
+            if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
+        }
         const size_t lds = lds_bytes(s);
 #define SN_LAUNCH_I8S(OT)                                                                                        \
     do {                                                                                                         \
