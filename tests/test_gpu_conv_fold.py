@@ -29,10 +29,8 @@ class fold:
 def _symmetric_bank(G, seed, scale=None):
     g = torch.Generator().manual_seed(seed)
     w = torch.rand((G, 9, 9, 9), generator=g) - 0.5
-    w = w + w.flip(2)
-    w = w + w.flip(3)           # exact: (a + b) + (c + d) is evaluated in the same order for mirrored positions? -> enforce
-    w = torch.maximum(w, w.flip(2))
-    w = torch.maximum(w, w.flip(3))
+    w = w + w.flip(2)           # a + b == b + a: symmetric in x bit for bit
+    w = w + w.flip(3)           # and in y, keeping the x symmetry (both mirrors add the same two numbers)
     if scale is None:
         scale = torch.logspace(-2, 0.3, G)
     return (w * scale.view(G, 1, 1, 1)).float().contiguous()
@@ -139,3 +137,26 @@ def test_guard_routes_a_symmetric_bank_it_cannot_serve(hip_device):
     assert (act.cpu().double() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
     fp32 = _hip.conv_bank(x.view(torch.uint8), b, l, want_act=True, want_out=True)
     assert torch.equal(act, fp32[0]) and torch.equal(out, fp32[1])
+
+
+def test_full_c2_batch_and_128_cubed_folded_equals_unfolded(hip_device):
+    """BASELINE C2's batch (32 x 64^3: eight tiles per workgroup, the halo ring wraps twice) and two 128^3 tiles (C3's tile
+    size): the folded kernel serves them and accumulates the same integers as the stride-4 kernel."""
+    from scene_net_amd.synthetic import synthetic_bank_spec
+    specs, names, lambdas, last = synthetic_bank_spec()
+    bank = go.geneo_bank(specs, (9, 9, 9))[:, 0].float().contiguous()
+    lam = go.effective_lambdas(lambdas, last, names).float()
+    assert torch.equal(bank, bank.flip(2)) and torch.equal(bank, bank.flip(3))   # the oracle's bank is symmetric too
+    b, l = bank.to(hip_device), lam.to(hip_device)
+    torch.manual_seed(11)
+    for shape in [(32, 1, 64, 64, 64), (2, 1, 128, 128, 128)]:
+        x = torch.rand(shape, device=hip_device) < 0.04
+        x[1] = True      # one completely full tile
+        x[0, :, : shape[2] // 2] = False
+        c0 = _hip.conv_i8_path_counts()
+        outs = [_hip.conv_bank(x, b, l, want_act=False, want_out=True)[1] for _ in range(3)]
+        assert _delta(c0, _hip.conv_i8_path_counts()) == (3, 0, 0)
+        with fold(False):
+            ref = _hip.conv_bank(x, b, l, want_act=False, want_out=True)[1]
+        for o in outs:
+            assert torch.equal(o, ref)
