@@ -1107,8 +1107,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         auto fold_unit = [&](const uint32_t (&r)[6], auto SLOT, i32x4 (&X)[4], uint32_t& centre) {
             constexpr int slot = decltype(SLOT)::value, J = slot % kFoldRows;
             constexpr bool single = fold_slot_single(slot / kFoldRows, J);
-            const uint32_t R0 = single ? r[0] : r[0] + r[3];
-            const uint32_t R1 = single ? r[1] : r[1] + r[4];
+            // (dwords 0 and 1 in one 64-bit add -- v_lshl_add_u64: bytes <= 2 per addend, nothing carries across)
+            const uint64_t R01 = single ? ((uint64_t)r[1] << 32 | r[0])
+                                        : ((uint64_t)r[1] << 32 | r[0]) + ((uint64_t)r[4] << 32 | r[3]);
+            const uint32_t R0 = (uint32_t)R01, R1 = (uint32_t)(R01 >> 32);
             const uint32_t R2 = single ? r[2] : r[2] + r[5];
 #ifdef SN_I8F_NOFOLD   // timing experiment (wrong results): the round without the y fold
             X[0][J] = (int)R0; X[1][J] = (int)R1; X[2][J] = (int)R2; X[3][J] = (int)R0;
