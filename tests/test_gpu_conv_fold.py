@@ -160,3 +160,29 @@ def test_full_c2_batch_and_128_cubed_folded_equals_unfolded(hip_device):
             ref = _hip.conv_bank(x, b, l, want_act=False, want_out=True)[1]
         for o in outs:
             assert torch.equal(o, ref)
+
+
+def test_random_shapes_folded_equals_unfolded(hip_device):
+    """Seeded sweep over grid extents (ragged in z and x, y any multiple of 16 -- partial y tiles, tiles smaller than a
+    workgroup's), batch sizes and kernel counts: folded == unfolded bit for bit, and both within tolerance of the oracle."""
+    rng = np.random.default_rng(20260104)
+    for case in range(14):
+        B = int(rng.integers(1, 4))
+        Z, X = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+        Y = 16 * int(rng.integers(1, 8))
+        G = int(rng.choice([1, 3, 7, 16, 17]))
+        occ = torch.from_numpy(rng.random((B, 1, Z, X, Y)) < rng.choice([0.02, 0.3, 0.9]))
+        bank = _symmetric_bank(G, 1000 + case)
+        lam = torch.from_numpy(((rng.random(G) - 0.3) / G).astype(np.float32))
+        x, b, l = occ.to(hip_device), bank.to(hip_device), lam.to(hip_device)
+        c0 = _hip.conv_i8_path_counts()
+        act_f, out_f = _run(x, b, l)
+        served, declined, routed = _delta(c0, _hip.conv_i8_path_counts())
+        assert (served, declined, routed) == ((G + 15) // 16, 0, 0), (case, (B, Z, X, Y, G), served, declined, routed)
+        with fold(False):
+            act_u, out_u = _run(x, b, l)
+        assert torch.equal(act_f, act_u) and torch.equal(out_f, out_u), (case, (B, Z, X, Y, G))
+        ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+        ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+        assert (act_f.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item()), case
+        assert (out_f.cpu().double() - ref_out).abs().max().item() < TOL, case
