@@ -61,7 +61,10 @@ template <bool kAligned, typename F>
 __device__ __forceinline__ void for_each_point(const double* __restrict__ pts, long p0, long p1, long gtid,
                                                long gstride, F&& f, const double* __restrict__ lab = nullptr) {
     constexpr bool kLab = std::is_invocable_v<F, double, double, double, long, double>;
-    constexpr int kDepth = 2;  // pairs in flight per iteration
+#ifndef SN_VOX_DEPTH
+#define SN_VOX_DEPTH 2
+#endif
+    constexpr int kDepth = SN_VOX_DEPTH;  // pairs in flight per iteration
     auto label = [&](long i) { return (kLab && lab) ? lab[i] : 0.0; };
     if (kAligned) {
         long q0 = p0 + (p0 & 1);  // first even point index >= p0
