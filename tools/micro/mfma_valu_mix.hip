@@ -15,7 +15,18 @@ __device__ __forceinline__ unsigned mix(unsigned x) {
     return x;
 }
 
-template <int KV>
+// kOp: which VALU instruction rides between the MFMAs: 0 v_alignbyte_b32, 1 v_perm_b32, 2 v_add_u32, 3 v_cvt_f32_i32,
+// 4 v_lshl_add_u64 (counted as ONE instruction per two dwords)
+template <int kOp>
+__device__ __forceinline__ int valu_op(int hi, int lo) {
+    if constexpr (kOp == 0) return (int)__builtin_amdgcn_alignbyte((unsigned)hi, (unsigned)lo, 1);
+    else if constexpr (kOp == 1) return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x02030405u);
+    else if constexpr (kOp == 2) return hi + lo;
+    else if constexpr (kOp == 3) return __float_as_int((float)lo) ^ hi;   // cvt + xor: two instructions
+    else return 0;
+}
+
+template <int KV, int kOp = 0>
 __global__ __launch_bounds__(512) void mix_kernel(int iters, int* out) {
     constexpr int NACC = 24;
     i32x4 acc[NACC];
@@ -34,7 +45,14 @@ __global__ __launch_bounds__(512) void mix_kernel(int iters, int* out) {
 #pragma unroll
             for (int k = 0; k < KV / 8; ++k) {
                 const int j = (v + 1 + k) & 7;
-                b[j][k & 3] = (int)__builtin_amdgcn_alignbyte((unsigned)b[j][(k + 1) & 3], (unsigned)b[j][k & 3], 1);
+                if constexpr (kOp == 4) {
+                    unsigned long long u = ((unsigned long long)(unsigned)b[j][1] << 32) | (unsigned)b[j][0];
+                    u += ((unsigned long long)(unsigned)b[j][3] << 32) | (unsigned)b[j][2];
+                    b[j][0] = (int)(unsigned)u;
+                    b[j][1] = (int)(unsigned)(u >> 32);
+                } else {
+                    b[j][k & 3] = valu_op<kOp>(b[j][(k + 1) & 3], b[j][k & 3]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -48,7 +66,7 @@ __global__ __launch_bounds__(512) void mix_kernel(int iters, int* out) {
     if (t == 0x7fffffff) out[0] = t;
 }
 
-template <int KV>
+template <int KV, int kOp = 0>
 void run_mix(int spin) {
     int* d = nullptr;
     if (hipMalloc(&d, 4) != hipSuccess) return;
@@ -56,11 +74,11 @@ void run_mix(int spin) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    for (int i = 0; i < spin; ++i) mix_kernel<KV><<<256, 512>>>(iters, d);
+    for (int i = 0; i < spin; ++i) mix_kernel<KV, kOp><<<256, 512>>>(iters, d);
     (void)hipDeviceSynchronize();
     const int reps = 10;
     (void)hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) mix_kernel<KV><<<256, 512>>>(iters, d);
+    for (int i = 0; i < reps; ++i) mix_kernel<KV, kOp><<<256, 512>>>(iters, d);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -68,7 +86,8 @@ void run_mix(int spin) {
     ms /= reps;
     const double trips_per_simd = 2.0 * iters;   // two waves per SIMD
     const double cyc = ms * 1e-3 * 2.4e9 / trips_per_simd;
-    printf("24 MFMA + %2d v_alignbyte per trip: %7.3f ms  %7.1f cycles per trip per SIMD at 2.4 GHz (24 MFMA = 384)\n", KV, ms, cyc);
+    static const char* names[] = {"v_alignbyte", "v_perm", "v_add_u32", "v_cvt_f32_i32 + v_xor", "v_lshl_add_u64"};
+    printf("24 MFMA + %2d %-22s per trip: %7.3f ms  %7.1f cycles per trip per SIMD at 2.4 GHz (24 MFMA = 384)\n", KV, names[kOp], ms, cyc);
     (void)hipFree(d);
 }
 
@@ -151,5 +170,12 @@ int main() {
     run_mix<24>(20);
     run_mix<48>(20);
     run_mix<96>(20);
+    run_mix<48, 1>(20);
+    run_mix<96, 1>(20);
+    run_mix<48, 2>(20);
+    run_mix<96, 2>(20);
+    run_mix<48, 3>(20);
+    run_mix<48, 4>(20);
+    run_mix<96, 4>(20);
     return 0;
 }
