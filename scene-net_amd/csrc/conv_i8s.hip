@@ -223,6 +223,17 @@ __device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, u
     o[3] = __builtin_amdgcn_perm(q1, p1, 0x07060302u);
 }
 
+// 3 x 4 byte transpose with a zero fourth row: o[r] = (a.byte r, b.byte r, c.byte r, 0) -- six v_perm_b32 (selector byte
+// 0x0c = the constant 0) instead of the eight of transpose4(a, b, c, 0)
+__device__ __forceinline__ void transpose3(uint32_t a, uint32_t b, uint32_t c, uint32_t (&o)[4]) {
+    const uint32_t p0 = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a0 b0 a1 b1
+    const uint32_t p1 = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a2 b2 a3 b3
+    o[0] = __builtin_amdgcn_perm(c, p0, 0x0c040100u);               // a0 b0 c0 0
+    o[1] = __builtin_amdgcn_perm(c, p0, 0x0c050302u);               // a1 b1 c1 0
+    o[2] = __builtin_amdgcn_perm(c, p1, 0x0c060100u);               // a2 b2 c2 0
+    o[3] = __builtin_amdgcn_perm(c, p1, 0x0c070302u);               // a3 b3 c3 0
+}
+
 template <int R>
 __device__ __forceinline__ uint32_t window(uint32_t hi, uint32_t lo) {   // bytes R .. R+3 of (hi : lo)
     if constexpr (R == 0) return lo;
@@ -1124,7 +1135,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         };
         auto centres = [&](uint32_t c0, uint32_t c1, uint32_t c2, i32x4 (&X)[4]) {
             uint32_t o[4];
-            transpose4(c0, c1, c2, 0u, o);
+            transpose3(c0, c1, c2, o);
 #pragma unroll
             for (int r = 0; r < 4; ++r) X[r][3] = (int)o[r];
         };
