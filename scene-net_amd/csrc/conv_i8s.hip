@@ -316,6 +316,59 @@ __device__ __forceinline__ void quantise_kernels(const Shape& s, int ntaps, floa
     }
 }
 
+// quantise_kernels for a bank that is symmetric in x and y (the folded kernel, after its symmetry check): only the 9 x 5 x 5
+// unique taps are visited, each standing for 1, 2 or 4 equal weights -- the same maximum, the same error sums up to the
+// order of the fp64 additions, and Q written where the folded table build reads it (dx <= 4, dy <= 4).
+__device__ __forceinline__ void quantise_kernels_folded(const Shape& s, float* bank_s, float* scale, double* bnd, int wave,
+                                                        int lane) {
+    constexpr int ntaps = 729, nuniq = 9 * 5 * 5;
+    const int g = 2 * wave + (lane >> 5), l32 = lane & 31;
+    auto tap_of = [](int u, int& mult) -> int {   // u = (dz * 5 + dx) * 5 + dy, dx, dy <= 4
+        const int dy = u % 5, r = u / 5, dx = r % 5, dz = r / 5;
+        mult = (dx < 4 ? 2 : 1) * (dy < 4 ? 2 : 1);
+        return (dz * 9 + dx) * 9 + dy;
+    };
+    float m = 0.0f;
+    if (g < s.G)
+        for (int u = l32; u < nuniq; u += 32) {
+            int mult;
+            const float a = fabsf(bank_s[g * ntaps + tap_of(u, mult)]);
+            m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);
+        }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const float u = __shfl_xor(m, o, 64);
+        m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
+    }
+    const double S = (m > 0.0f) ? kQMax / (double)m : 0.0;
+    const double invS = (double)m / kQMax;
+    double ep = 0.0, en = 0.0;
+    if (g < s.G)
+        for (int u = l32; u < nuniq; u += 32) {
+            int mult;
+            const int t = g * ntaps + tap_of(u, mult);
+            if (m > 0.0f) {
+                const double w = (double)bank_s[t];
+                const int Q = __double2int_rn(w * S);
+                const double e = ((double)Q * invS - w) * (double)mult;
+                ep += e > 0.0 ? e : 0.0;
+                en += e < 0.0 ? -e : 0.0;
+                bank_s[t] = __int_as_float(Q);
+            } else {
+                bank_s[t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
+            }
+        }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        ep += __shfl_xor(ep, o, 64);
+        en += __shfl_xor(en, o, 64);
+    }
+    if (l32 == 0) {
+        scale[g] = (m != m) ? m : (float)((double)m / kQMax);
+        bnd[g] = ep > en ? ep : en;
+    }
+}
+
 // the guard's decision: all workgroups take it from the same numbers
 template <typename OT>
 __device__ __forceinline__ bool bound_exceeded(const Shape& s, const double* bnd, const float* __restrict__ lambdas,
@@ -999,7 +1052,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         return;
     }
     SN_ST(6);   // (symmetry checked)
-    quantise_kernels(s, ntaps, bank_s, scale, bnd, wave, lane);
+    quantise_kernels_folded(s, bank_s, scale, bnd, wave, lane);
     lds_barrier();
     SN_ST(2);
     {
