@@ -1195,19 +1195,27 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         constexpr std::integral_constant<int, 0> H0{};
         constexpr std::integral_constant<int, 1> H1{};
         // operands of step ST at lane base xb, un-pipelined (a tile's first round)
-        auto build_step = [&](const uint8_t* xb, auto ST, i32x4 (&X)[2][4]) {
-            constexpr int st = decltype(ST)::value;
-            constexpr std::integral_constant<int, st * kFoldRows + 0> L0{};
-            constexpr std::integral_constant<int, st * kFoldRows + 1> L1{};
-            constexpr std::integral_constant<int, st * kFoldRows + 2> L2{};
+        // a round's first step, un-pipelined: its six units' raw dwords and their folding.  (Requesting even the first two
+        // units a round early, behind the previous round's last MFMAs, makes hipcc spill around the epilogue: 76 bytes.)
+        uint32_t fraw[6][6];
+        auto first_load_a = [&](const uint8_t* xb) {
+            constexpr std::integral_constant<int, 0> L0{};
+            load_unit(xb, L0, H0, fraw[0]); load_unit(xb, L0, H1, fraw[1]);
+        };
+        auto first_load_b = [&](const uint8_t* xb) {
+            constexpr std::integral_constant<int, 1> L1{};
+            constexpr std::integral_constant<int, 2> L2{};
+            load_unit(xb, L1, H0, fraw[2]); load_unit(xb, L1, H1, fraw[3]);
+            load_unit(xb, L2, H0, fraw[4]); load_unit(xb, L2, H1, fraw[5]);
+        };
+        auto first_fold = [&](i32x4 (&X)[2][4]) {
+            constexpr std::integral_constant<int, 0> L0{};
+            constexpr std::integral_constant<int, 1> L1{};
+            constexpr std::integral_constant<int, 2> L2{};
             uint32_t c00, c01, c10, c11, c20, c21;
-            uint32_t r00[6], r01[6], r10[6], r11[6], r20[6], r21[6];
-            load_unit(xb, L0, H0, r00); load_unit(xb, L0, H1, r01);
-            load_unit(xb, L1, H0, r10); load_unit(xb, L1, H1, r11);
-            load_unit(xb, L2, H0, r20); load_unit(xb, L2, H1, r21);
-            fold_unit(r00, L0, X[0], c00); fold_unit(r01, L0, X[1], c01);
-            fold_unit(r10, L1, X[0], c10); fold_unit(r11, L1, X[1], c11);
-            fold_unit(r20, L2, X[0], c20); fold_unit(r21, L2, X[1], c21);
+            fold_unit(fraw[0], L0, X[0], c00); fold_unit(fraw[1], L0, X[1], c01);
+            fold_unit(fraw[2], L1, X[0], c10); fold_unit(fraw[3], L1, X[1], c11);
+            fold_unit(fraw[4], L2, X[0], c20); fold_unit(fraw[5], L2, X[1], c21);
             centres(c00, c10, c20, X[0]);
             centres(c01, c11, c21, X[1]);
         };
@@ -1240,7 +1248,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             else if constexpr (piece >= 8 - kAhead && nst >= 0)
                 pipe_load(nxb, std::integral_constant<int, (nst < 0 ? 0 : nst)>{}, std::integral_constant<int, piece - (8 - kAhead)>{});
         };
-        constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, 1> S1{};
         constexpr std::integral_constant<int, 2> S2{};
         constexpr std::integral_constant<int, 3> S3{};
@@ -1284,8 +1291,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             };
             i32x4 wa[3], wb[3];
             load_w(0, wa);
-            build_step(xb, S0, Xa);
-            pipe_open(xb, S1);   // (not carried over from the previous round: twelve registers less across the epilogue)
+            first_load_a(xb);
+            first_load_b(xb);
+            first_fold(Xa);
+            pipe_open(xb, S1);
             load_w(1, wb);
             __builtin_amdgcn_sched_barrier(0);
             mma_step(wa, Xa, true, [&](auto v) { pipe_piece(xb, S1, v, Xb, xb, S2); });
