@@ -60,6 +60,9 @@ def parse():
                     help="record the HIP events that time the stages on every N-th timed step; 0 (default) = "
                          "4 (1 below 8 steps).  [measured] a record costs ~2.5 us of GPU time: 0.2547 / "
                          "0.2446 / 0.2417 ms per step with the four records on every / every 4th / one timed step")
+    ap.add_argument("--sustain-ms", type=float, default=400.0,
+                    help="also time the same eager step back to back over at least this much wall time "
+                         "(`value_sustained`; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 code path on a one-GPU box: every rank uses cuda:0, process group over gloo (not a "
@@ -436,6 +439,24 @@ def main():
         msg = f"{type(exc).__name__}: {exc}"[:200]
         graph_info = {"skipped": msg} if "skipped" in msg else {"error": msg}
 
+    # which BASELINE config this run is (derived from the arguments, never assumed)
+    if (B, args.points, args.grid) == (32, 100_000, 64):
+        wl_tag = "C2"
+    elif args.grid == 128 and B == 32:
+        wl_tag = "C3 per-GPU share (256 tiles / 8 GPUs)"
+    else:
+        wl_tag = "custom"
+
+    # ---- sustained figure: the same eager step, back to back, over >= --sustain-ms of wall time (no events inside):
+    # long enough for an external sampler (rocm-smi, the driver's gpu_busy probe) to see the GPU busy, and a check on the
+    # headline's clock state -- `value` is 20 steps = 3-4 ms
+    sustained = None
+    if args.sustain_ms > 0:
+        n_s = max(args.steps, int(args.sustain_ms / max(dt / args.steps * 1e3, 1e-3)) + 1)
+        dt_s, _ = timed_job(lambda: step(False), n_s)
+        sustained = {"value": B * n_s * n_gpus / dt_s, "ms_per_step": dt_s / n_s * 1e3, "steps": n_s,
+                     "wall_s": dt_s}
+
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from separate rocprofv3 --pmc passes
     if os.path.exists(tpath):
@@ -451,9 +472,11 @@ def main():
         # contraction on the fp32 matrix pipe (K1 -> K2 -> conv_bank_kernel, same fences, same batch)
         "value_cold": tiles_done / dt_cold, "ms_per_step_cold": dt_cold / args.steps * 1e3,
         "value_fp32": B * n32 * n_gpus / dt_fp32, "ms_per_step_fp32": dt_fp32 / n32 * 1e3, "steps_fp32": n32,
+        "value_sustained": sustained["value"] if sustained else None,
+        "sustained": sustained,
         "clock_state": f"value: after {args.spinup_ms:.0f} ms untimed spin-up of the same step; value_cold: none",
         "rccl_ranks": rccl_ranks, "per_rank_tiles_per_s": per_rank,
-        "config": {"workload": f"C2: {B} tiles/GPU x {args.points} points (fp64 xyz, UTM-scale), {args.grid}^3 voxel "
+        "config": {"workload": f"{wl_tag}: {B} tiles/GPU x {args.points} points (fp64 xyz, UTM-scale), {args.grid}^3 voxel "
                                f"grid, {G} GENEO kernels {KERNEL_SIZE[0]}^3 (cy 6, cone 5, neg 5); conv on the int8 "
                                f"matrix cores: binary occupancy x 24-bit fixed-point weights (3 int8 digits), exact "
                                f"int32 accumulation, fp32 head",

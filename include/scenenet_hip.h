@@ -135,6 +135,27 @@ int sn_conv_bank(const void* x, int x_dtype, const float* bank, const float* lam
                  int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
                  void* act, void* out, int out_dtype, sn_stream_t stream);
 
+/* The same contraction for a bank whose per-bank work was done once, ahead of the launch (round 3).
+ * SceneNet.forward rebuilds its kernels from the parameters on every call (SCENE_Net.py:322-327); everything the int8
+ * contraction derives from the bank alone -- the x/y symmetry verdict, the 24-bit fixed-point weights, the worst-case
+ * quantisation error per kernel, the digit table of the folded operand plan -- is a function of those weights, so
+ * sn_conv_bank_prep computes it in one small launch (16 workgroups; it can run on a side stream next to the
+ * voxelisation) into `prep`: caller-owned device memory, 16-byte aligned, SN_CONV_PREP_BYTES per group of 16 kernels
+ * (ceil(G / 16) groups).  sn_conv_bank_prepared is sn_conv_bank with that blob: SN_OCC8 input and a 9 x 9 x 9 bank run
+ * the z-walk kernel (csrc/conv_i8z.inc: every input plane fetched and y-folded once per 8 x 64 column, no per-workgroup
+ * prologue); the blob also holds the launch's route flag (bank not symmetric: the unfolded body runs in the same
+ * launch; quantisation bound over the tolerance: the gated fp32 launch behind it takes over), so a captured graph owns
+ * its flag.  One blob serves the launches of ONE stream at a time.  Results are bit-identical to sn_conv_bank's.
+ * Every other dtype / shape: forwarded to sn_conv_bank (prep may be null). */
+#define SN_CONV_PREP_BYTES 16384
+int sn_conv_bank_prep(const float* bank, int G, int kz, int kx, int ky, void* prep, sn_stream_t stream);
+int sn_conv_bank_prepared(const void* x, int x_dtype, const float* bank, const float* lambdas, void* prep,
+                          int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
+                          void* act, void* out, int out_dtype, sn_stream_t stream);
+/* Diagnostics: how many waves of the int8 kernels ever gave up a bounded LDS hand-over spin (must stay 0: a non-zero
+ * count means a launch may have read a ring slot that had not landed).  Synchronises the device. */
+int sn_conv_i8_spin_timeouts(unsigned long long* count);
+
 /* The same forward output through linearity, without materialising the bank activations:
  *   relu(tanh(sum_g lambda_g conv3d(x, K_g))) == relu(tanh(conv3d(x, sum_g lambda_g K_g)))
  * (equal to 5e-16 in the reference's fp64; core/models/SCENE_Net.py:322-339).  One combined kernel

@@ -35,6 +35,9 @@ SYMBOLS = {
     "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_effective_lambdas": (c_int, [_P, _P, _I, _I, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_conv_bank_prep": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "sn_conv_bank_prepared": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_conv_i8_spin_timeouts": (c_int, [_P]),
     "sn_conv_fused": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sn_conv_fused_supported": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
     "sn_forward_auto": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
@@ -62,6 +65,7 @@ SYMBOLS = {
     "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
     "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
 }
+SN_CONV_PREP_BYTES = 16384
 SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE, SN_LOSS_WBCE = 1, 2, 4, 8
 SN_LOSS_MAX_BINS = 16
 SN_OCC_PARTS = 16
@@ -115,6 +119,13 @@ def conv_i8_path_counts() -> Tuple[int, int, int]:
     buf = (ctypes.c_ulonglong * 3)()
     _check(load().sn_conv_i8_path_counts(ctypes.cast(buf, ctypes.c_void_p)), "sn_conv_i8_path_counts")
     return int(buf[0]), int(buf[1]), int(buf[2])
+
+
+def conv_i8_spin_timeouts() -> int:
+    """Waves of the int8 kernels that ever gave up a bounded LDS hand-over spin (must be 0); synchronises."""
+    buf = (ctypes.c_ulonglong * 1)()
+    _check(load().sn_conv_i8_spin_timeouts(ctypes.cast(buf, ctypes.c_void_p)), "sn_conv_i8_spin_timeouts")
+    return int(buf[0])
 
 
 def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str = "tensor") -> Optional[int]:
@@ -233,10 +244,28 @@ def geneo_bank_lambdas(params: torch.Tensor, kinds: torch.Tensor, kernel_size: S
 
 
 @_on_tensor_device
+def conv_bank_prep(bank: torch.Tensor, prep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The per-bank work of the int8 contraction, once (sn_conv_bank_prep): symmetry verdict, 24-bit fixed-point weights,
+    error bounds and digit table of `bank` [G,kz,kx,ky] f32 into a caller-owned blob (uint8, SN_CONV_PREP_BYTES per group
+    of 16 kernels), which conv_bank(..., prep=) then uses.  One blob serves the launches of one stream at a time."""
+    G, kz, kx, ky = bank.shape
+    nbytes = SN_CONV_PREP_BYTES * ((G + 15) // 16)
+    if prep is None:
+        prep = torch.empty(nbytes, dtype=torch.uint8, device=bank.device)
+    elif prep.dtype != torch.uint8 or prep.numel() < nbytes:
+        raise HipLibraryError(f"prep must be uint8 with at least {nbytes} bytes")
+    rc = load().sn_conv_bank_prep(_ptr(bank, torch.float32, "bank"), G, kz, kx, ky, _ptr(prep, torch.uint8, "prep"),
+                                  _stream())
+    _check(rc, "sn_conv_bank_prep")
+    return prep
+
+
+@_on_tensor_device
 def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tensor], want_act: bool = False,
-              want_out: bool = True, out_dtype: Optional[torch.dtype] = None):
+              want_out: bool = True, out_dtype: Optional[torch.dtype] = None, prep: Optional[torch.Tensor] = None):
     """x [B,1,Z,X,Y] (f32|f64|u8|bool), bank [G,kz,kx,ky] f32, lambdas [G] f32 (effective) ->
-    (act [B,G,Z,X,Y] | None, out [B,1,Z,X,Y] | None) of out_dtype (sn_conv_bank)."""
+    (act [B,G,Z,X,Y] | None, out [B,1,Z,X,Y] | None) of out_dtype (sn_conv_bank; with `prep` = conv_bank_prep(bank):
+    sn_conv_bank_prepared -- same results bit for bit, the per-bank work not repeated)."""
     if x.dim() != 5 or x.shape[1] != 1:
         raise HipLibraryError(f"x must be [B,1,Z,X,Y] (got {tuple(x.shape)})")
     if x.dtype not in _DT or x.dtype == torch.bfloat16:
@@ -247,6 +276,15 @@ def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tenso
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
     act = torch.empty((B, G, Z, X, Y), dtype=out_dtype, device=x.device) if want_act else None
     out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device) if want_out else None
+    if prep is not None:
+        if prep.dtype != torch.uint8 or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
+            raise HipLibraryError("prep: not a blob of conv_bank_prep for this bank")
+        rc = load().sn_conv_bank_prepared(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                                          _ptr(lambdas, torch.float32, "lambdas"), _ptr(prep, torch.uint8, "prep"),
+                                          B, Z, X, Y, G, kz, kx, ky, _ptr(act, None, "act"), _ptr(out, None, "out"),
+                                          _DT_OUT[out_dtype], _stream())
+        _check(rc, "sn_conv_bank_prepared")
+        return act, out
     rc = load().sn_conv_bank(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
                              _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky,
                              _ptr(act, None, "act"), _ptr(out, None, "out"), _DT_OUT[out_dtype], _stream())

@@ -316,23 +316,22 @@ __device__ __forceinline__ void quantise_kernels(const Shape& s, int ntaps, floa
     }
 }
 
-// quantise_kernels for a bank that is symmetric in x and y (the folded kernel, after its symmetry check): only the 9 x 5 x 5
-// unique taps are visited, each standing for 1, 2 or 4 equal weights -- the same maximum, the same error sums up to the
-// order of the fp64 additions, and Q written where the folded table build reads it (dx <= 4, dy <= 4).
-__device__ __forceinline__ void quantise_kernels_folded(const Shape& s, float* bank_s, float* scale, double* bnd, int wave,
-                                                        int lane) {
-    constexpr int ntaps = 729, nuniq = 9 * 5 * 5;
-    const int g = 2 * wave + (lane >> 5), l32 = lane & 31;
+// one kernel's part of quantise_kernels_folded on the 32 lanes of a half wave (l32): `w` = the kernel's 729 fp32 weights in
+// LDS (overwritten by Q at the unique taps); shared with the stand-alone preparation kernel (conv_i8z.inc), so that both
+// produce the same bits
+__device__ __forceinline__ void quantise_folded_half(float* w, bool valid, int l32, float& scale_out, double& bnd_out,
+                                                     double& pos_out, double& neg_out) {
+    constexpr int nuniq = 9 * 5 * 5;
     auto tap_of = [](int u, int& mult) -> int {   // u = (dz * 5 + dx) * 5 + dy, dx, dy <= 4
         const int dy = u % 5, r = u / 5, dx = r % 5, dz = r / 5;
         mult = (dx < 4 ? 2 : 1) * (dy < 4 ? 2 : 1);
         return (dz * 9 + dx) * 9 + dy;
     };
     float m = 0.0f;
-    if (g < s.G)
+    if (valid)
         for (int u = l32; u < nuniq; u += 32) {
             int mult;
-            const float a = fabsf(bank_s[g * ntaps + tap_of(u, mult)]);
+            const float a = fabsf(w[tap_of(u, mult)]);
             m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);
         }
 #pragma unroll
@@ -342,36 +341,55 @@ __device__ __forceinline__ void quantise_kernels_folded(const Shape& s, float* b
     }
     const double S = (m > 0.0f) ? kQMax / (double)m : 0.0;
     const double invS = (double)m / kQMax;
-    double ep = 0.0, en = 0.0;
-    if (g < s.G)
+    double ep = 0.0, en = 0.0, qp = 0.0, qn = 0.0;
+    if (valid)
         for (int u = l32; u < nuniq; u += 32) {
             int mult;
-            const int t = g * ntaps + tap_of(u, mult);
+            const int t = tap_of(u, mult);
             if (m > 0.0f) {
-                const double w = (double)bank_s[t];
-                const int Q = __double2int_rn(w * S);
-                const double e = ((double)Q * invS - w) * (double)mult;
+                const double wv = (double)w[t];
+                const int Q = __double2int_rn(wv * S);
+                const double e = ((double)Q * invS - wv) * (double)mult;
                 ep += e > 0.0 ? e : 0.0;
                 en += e < 0.0 ? -e : 0.0;
-                bank_s[t] = __int_as_float(Q);
+                qp += Q > 0 ? (double)Q * (double)mult : 0.0;   // (exact: |Q| < 2^23, 729 taps)
+                qn += Q < 0 ? -(double)Q * (double)mult : 0.0;
+                w[t] = __int_as_float(Q);
             } else {
-                bank_s[t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
+                w[t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
             }
         }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
         ep += __shfl_xor(ep, o, 64);
         en += __shfl_xor(en, o, 64);
+        qp += __shfl_xor(qp, o, 64);
+        qn += __shfl_xor(qn, o, 64);
     }
+    scale_out = (m != m) ? m : (float)((double)m / kQMax);
+    bnd_out = ep > en ? ep : en;
+    pos_out = qp;
+    neg_out = qn;
+}
+
+// quantise_kernels for a bank that is symmetric in x and y (the folded kernel, after its symmetry check): only the 9 x 5 x 5
+// unique taps are visited, each standing for 1, 2 or 4 equal weights -- the same maximum, the same error sums up to the
+// order of the fp64 additions, and Q written where the folded table build reads it (dx <= 4, dy <= 4).
+__device__ __forceinline__ void quantise_kernels_folded(const Shape& s, float* bank_s, float* scale, double* bnd, int wave,
+                                                        int lane) {
+    const int g = 2 * wave + (lane >> 5), l32 = lane & 31;
+    float sc;
+    double bd, qp, qn;
+    quantise_folded_half(bank_s + (g < s.G ? g : 0) * 729, g < s.G, l32, sc, bd, qp, qn);
     if (l32 == 0) {
-        scale[g] = (m != m) ? m : (float)((double)m / kQMax);
-        bnd[g] = ep > en ? ep : en;
+        scale[g] = sc;
+        bnd[g] = bd;
     }
 }
 
 // the guard's decision: all workgroups take it from the same numbers
-template <typename OT>
-__device__ __forceinline__ bool bound_exceeded(const Shape& s, const double* bnd, const float* __restrict__ lambdas,
+template <typename OT, typename SH>
+__device__ __forceinline__ bool bound_exceeded(const SH& s, const double* bnd, const float* __restrict__ lambdas,
                                                const OT* act, const OT* out) {
     if (!(s.tol > 0.0f)) return false;
     double worst = 0.0, mixed = 0.0;
@@ -384,13 +402,17 @@ __device__ __forceinline__ bool bound_exceeded(const Shape& s, const double* bnd
 
 // One round's epilogue, shared by the kernels of this file: recombine the three digit sums, store the bank activations
 // (if requested), mix the 16 kernels into the head.  acc[d][v]: digit plane d of accumulator tile v = 4 h + r.
-template <typename OT>
-__device__ __forceinline__ void finish_round(const Shape& s, const TileCoord& c, int lz, int lx, int n, int q,
+template <typename OT, typename SH>
+__device__ __forceinline__ void finish_round(const SH& s, const TileCoord& c, int lz, int lx, int n, int q,
                                              i32x4 (&acc)[3][NV], const float* scale, const float* lamsc,
                                              const float* lamhi, OT* __restrict__ act, OT* __restrict__ out, size_t V) {
     const int gz = c.z0 + lz;
     if (gz >= s.Z) return;
+#ifdef SN_I8F_NOEPI
+    if (true) {
+#else
     if (s.dbg & 1) {
+#endif
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -948,7 +970,7 @@ __device__ __forceinline__ void conv_occ_i8s_body(const uint8_t* __restrict__ x,
         SN_WT(5, t_e);
         SN_WT(6, t_tile);
     }
-    if (!healthy && lane == 0) flags[1] = 1;
+    if (!healthy && lane == 0) atomicAdd(&g_fold_counts[3], 1ull);   // reported: sn_conv_i8_spin_timeouts
     SN_ST(5);
 }
 
@@ -1321,7 +1343,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             wave_signal(&landed[(it + 2) % kNB], lane);
         }
     }
-    if (!healthy && lane == 0) flags[1] = 1;
+    if (!healthy && lane == 0) atomicAdd(&g_fold_counts[3], 1ull);   // reported: sn_conv_i8_spin_timeouts
     SN_ST(5);
 }
 
@@ -1409,6 +1431,37 @@ bool plan_rows(int kz, int kx, int XP, RowPlan& p, int& RQ) {
     return true;
 }
 
+// tile shape and row plan of the stride-4 kernel for a (B, Z, X, Y) grid with 9 x 9 kernel rows: false = not served
+bool plan_stride4(Shape& s, int B, int Z, int X, int Y, int kz, int kx, int cus) {
+    static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
+    bool found = false;
+    for (const auto& c : cand) {
+        s.TZ = c[0]; s.TX = c[1];   // (TX / 2 a power of two: the kernel splits a round index by shift and mask)
+        s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
+        const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
+        if (nt > 0x7fffffff) return false;
+        s.ntiles = (int)nt;
+        s.ZP = s.TZ + kz - 1;
+        s.XP = (s.TX + kx - 1) | 1;   // odd: rows of different z planes can pair up 2 (mod 4) apart
+        if (!plan_rows(kz, kx, s.XP, s.plan, s.RQ)) return false;
+        s.ODD = s.RQ & 1;
+        s.NP = s.RQ / 2;
+        s.NT = (s.RQ + 3) / 4;
+        s.NTS = (s.NT + 2 * s.ODD + 3) / 4;
+        s.KS = s.NP + s.NTS;
+        // one instantiation: 81 kernel rows (9 x 9) = 10 pair steps, 6 quads, an odd row.  (The run-time form of the step
+        // structure compiles, and is correct, but spills: hipcc keeps two copies of the accumulators across its joins.)
+        if (s.NP != 10 || s.NT != 6 || s.ODD != 1) return false;
+        if (s.ZP * s.XP > 32767) continue;
+        if (lds_bytes(s) > (size_t)kMaxLds) continue;
+        found = true;
+        if (s.ntiles >= 4 * cus) break;
+    }
+    return found;
+}
+
+#include "conv_i8z.inc"
+
 }  // namespace
 
 namespace sn {
@@ -1437,30 +1490,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     const char* stat = getenv("SN_CONV_I8S_STATIC");
     s.dynamic = !(stat && stat[0] == '1');
     const int cus = num_cus();
-    static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {1, 4}, {1, 2}};
-    bool found = false;
-    for (const auto& c : cand) {
-        s.TZ = c[0]; s.TX = c[1];   // (TX / 2 a power of two: the kernel splits a round index by shift and mask)
-        s.nzt = (Z + s.TZ - 1) / s.TZ; s.nxt = (X + s.TX - 1) / s.TX;
-        const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
-        if (nt > 0x7fffffff) return 1;
-        s.ntiles = (int)nt;
-        s.ZP = s.TZ + kz - 1;
-        s.XP = (s.TX + kx - 1) | 1;   // odd: rows of different z planes can pair up 2 (mod 4) apart
-        if (!plan_rows(kz, kx, s.XP, s.plan, s.RQ)) return 1;
-        s.ODD = s.RQ & 1;
-        s.NP = s.RQ / 2;
-        s.NT = (s.RQ + 3) / 4;
-        s.NTS = (s.NT + 2 * s.ODD + 3) / 4;
-        s.KS = s.NP + s.NTS;
-        // one instantiation: 81 kernel rows (9 x 9) = 10 pair steps, 6 quads, an odd row.  (The run-time form of the step
-        // structure compiles, and is correct, but spills: hipcc keeps two copies of the accumulators across its joins.)
-        if (s.NP != 10 || s.NT != 6 || s.ODD != 1) return 1;
-        if (s.ZP * s.XP > 32767) continue;
-        if (lds_bytes(s) > (size_t)kMaxLds) continue;
-        found = true;
-        if (s.ntiles >= 4 * cus) break;
-    }
+    const bool found = plan_stride4(s, B, Z, X, Y, kz, kx, cus);
     if (!found) return 1;
     // quantisation guard (see the header): tolerance on the worst-case activation error of the int8 path
     s.tol = sn::option_conv_i8_tolerance();
@@ -1531,7 +1561,128 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     return SN_OK;
 }
 
+// The z-walk over pre-folded planes (conv_i8z.inc) for a bank prepared by sn_conv_bank_prep.  Returns SN_OK, an error, or
+// 1 when this shape is not served here (caller: sn_conv_bank's own kernels).
+int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint8_t* prep, int B, int Z, int X, int Y,
+                 int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
+                 hipStream_t stream) {
+    if (ky != 9 || kz != 9 || kx != 9 || Y % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || G > 16) return 1;
+    if (act && (reinterpret_cast<uintptr_t>(act) & 15)) return 1;
+    if (out && (reinterpret_cast<uintptr_t>(out) & 15)) return 1;
+    if (!prep || (reinterpret_cast<uintptr_t>(prep) & 15)) return 1;
+    if (sn::option_conv_skip_empty_tiles() || !sn::option_conv_i8_fold() || sn::option_conv_i8_legacy()) return 1;
+    const int cus = num_cus();
+    // the stride-4 kernel's plan: what the launch runs, in place, for a bank that is not symmetric
+    Shape s4;
+    memset(&s4, 0, sizeof(s4));
+    s4.B = B; s4.Z = Z; s4.X = X; s4.Y = Y; s4.G = G; s4.kz = kz; s4.kx = kx;
+    s4.Gtot = Gtot; s4.g0 = g0; s4.head = head;
+    s4.gate = sn::current_gate();
+    s4.nyt = (Y + TY - 1) / TY;
+    s4.dynamic = 1;
+    if (!plan_stride4(s4, B, Z, X, Y, kz, kx, cus)) return 1;
+    s4.tol = sn::option_conv_i8_tolerance();
+    s4.route = reinterpret_cast<int32_t*>(prep + kPrepRoute);
+    ZShape z;
+    memset(&z, 0, sizeof(z));
+    z.B = B; z.Z = Z; z.X = X; z.Y = Y; z.G = G; z.Gtot = Gtot; z.g0 = g0; z.head = head;
+    z.gate = s4.gate;
+    z.tol = s4.tol;
+    z.route = s4.route;
+    z.nxt = (X + kZTX - 1) / kZTX;
+    z.nyt = (Y + TY - 1) / TY;
+    const long long ncol = (long long)B * z.nxt * z.nyt;
+    if (ncol > (long long)cus * kZMaxJobs) return 1;
+    // z segments per column: whole columns when they fill the chip evenly, else the split that minimises the planes the
+    // busiest workgroup walks (a segment re-fetches 8 halo planes)
+    int best_seg = 1;
+    long long best_cost = -1;
+    const int max_seg = (Z + 7) / 8;
+    for (int ns = 1; ns <= max_seg; ++ns) {
+        const int lz = (Z + ns - 1) / ns;
+        const int nseg = (Z + lz - 1) / lz;
+        const long long jobs = ncol * nseg;
+        const long long per_wg = (jobs + cus - 1) / cus;
+        if (per_wg > kZMaxJobs) continue;
+        const long long cost = per_wg * (lz + 8) + kZD;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_seg = ns; }
+    }
+    if (best_cost < 0) return 1;
+    z.LZ = (Z + best_seg - 1) / best_seg;
+    z.nseg = (Z + z.LZ - 1) / z.LZ;
+    z.PL = z.LZ + 8;
+    const long long njobs = ncol * z.nseg;
+    if (njobs > 0x7fffffff) return 1;
+    z.njobs = (int)njobs;
+    const int grid = (int)(njobs < cus ? njobs : cus);
+    const int per_wg = (z.njobs + grid - 1) / grid;
+    if (per_wg > kZMaxJobs) return 1;
+    if (!division_magic((unsigned)z.PL, (unsigned)(per_wg * z.PL + 64), z.pl_magic)) return 1;
+    z.swizzle = (grid % 8 == 0) ? 1 : 0;
+    const size_t lds_z = lds_bytes_zwalk(), lds_4 = lds_bytes(s4);
+    const size_t lds = lds_z > lds_4 ? lds_z : lds_4;
+    if (lds > (size_t)kMaxLds) return 1;
+#define SN_LAUNCH_I8Z(OT)                                                                                        \
+    do {                                                                                                         \
+        auto kern = conv_occ_i8z_kernel<OT>;                                                                     \
+        if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
+            return check_launch("sn_conv_bank_prepared(i8z: hipFuncSetAttribute)");                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, (const uint8_t*)prep, z, s4, \
+                           (OT*)act, (OT*)out);                                                                  \
+    } while (0)
+    if (out_dtype == SN_F32) SN_LAUNCH_I8Z(float);
+    else SN_LAUNCH_I8Z(double);
+#undef SN_LAUNCH_I8Z
+    if (int rc = check_launch("sn_conv_bank_prepared(i8z)")) return rc;
+    if (z.tol > 0.0f) {
+        // the same launch on the fp32 matrix pipe, enqueued behind: runs only if the guard sent it there
+        sn::GateScope guard(z.route, 1);
+        return sn::conv_bank_group(x, SN_U8, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky, act, out,
+                                   out_dtype, reinterpret_cast<sn_stream_t>(stream));
+    }
+    return SN_OK;
+}
+
 }  // namespace sn
+
+extern "C" int sn_conv_bank_prep(const float* bank, int G, int kz, int kx, int ky, void* prep, sn_stream_t stream) {
+    if (!bank || !prep) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prep: null pointer");
+    if (G <= 0 || kz <= 0 || kx <= 0 || ky <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prep: non-positive extent");
+    if (reinterpret_cast<uintptr_t>(prep) & 15) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prep: prep must be 16-byte aligned");
+    if (kz != 9 || kx != 9 || ky != 9) return SN_OK;   // other shapes: sn_conv_bank_prepared does not read the blob
+    for (int g0 = 0; g0 < G; g0 += 16) {
+        const int gc = (G - g0 < 16) ? G - g0 : 16;
+        hipLaunchKernelGGL(conv_prep_kernel, dim3(16), dim3(256), 0, sn::as_stream(stream), bank + (size_t)g0 * 729, gc,
+                           static_cast<uint8_t*>(prep) + (size_t)(g0 / 16) * SN_CONV_PREP_BYTES);
+    }
+    return sn::check_launch("sn_conv_bank_prep");
+}
+
+extern "C" int sn_conv_bank_prepared(const void* x, int x_dtype, const float* bank, const float* lambdas, void* prep,
+                                     int B, int Z, int X, int Y, int G, int kz, int kx, int ky, void* act, void* out,
+                                     int out_dtype, sn_stream_t stream) {
+    if (!x || !bank) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prepared: null x or bank");
+    if (!act && !out) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prepared: both act and out are null");
+    if (out && !lambdas) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prepared: out needs lambdas");
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prepared: non-positive extent");
+    if (out_dtype != SN_F32 && out_dtype != SN_F64)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_bank_prepared: out_dtype %d", out_dtype);
+    if (x_dtype != SN_OCC8 || !prep || kz != 9 || kx != 9 || ky != 9 || (size_t)B * Z * X * Y > (size_t)1 << 40)
+        return sn_conv_bank(x, x_dtype, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, act, out, out_dtype, stream);
+    for (int g0 = 0; g0 < G; g0 += 16) {
+        const int gc = (G - g0 < 16) ? G - g0 : 16;
+        const int head = G > 16 ? ((g0 > 0 ? 1 : 0) | (g0 + gc >= G ? 2 : 0)) : 2;
+        int rc = sn::conv_occ_i8z((const uint8_t*)x, bank + (size_t)g0 * 729, lambdas ? lambdas + g0 : nullptr,
+                                  static_cast<uint8_t*>(prep) + (size_t)(g0 / 16) * SN_CONV_PREP_BYTES, B, Z, X, Y, gc, G,
+                                  g0, head, kz, kx, ky, act, out, out_dtype, sn::as_stream(stream));
+        if (rc == 1)   // shape not served by the z-walk: this group through sn_conv_bank's own kernels
+            rc = sn::conv_bank_group(x, x_dtype, bank + (size_t)g0 * 729, lambdas ? lambdas + g0 : nullptr, B, Z, X, Y, gc,
+                                     G, g0, head, kz, kx, ky, act, out, out_dtype, stream);
+        if (rc != SN_OK) return rc;
+    }
+    return SN_OK;
+}
 
 extern "C" int sn_conv_i8_path_counts(unsigned long long* counts3) {
     if (!counts3) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_i8_path_counts: null pointer");
@@ -1539,6 +1690,15 @@ extern "C" int sn_conv_i8_path_counts(unsigned long long* counts3) {
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_counts), sizeof(h)) != hipSuccess)
         return sn::check_launch("sn_conv_i8_path_counts");
     counts3[0] = h[0]; counts3[1] = h[1]; counts3[2] = h[2];
+    return SN_OK;
+}
+
+extern "C" int sn_conv_i8_spin_timeouts(unsigned long long* count) {
+    if (!count) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_i8_spin_timeouts: null pointer");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_counts), sizeof(h)) != hipSuccess)
+        return sn::check_launch("sn_conv_i8_spin_timeouts");
+    *count = h[3];
     return SN_OK;
 }
 

@@ -296,6 +296,15 @@ def dump_real_tile_subset():
     print("ts40k_sample575_subset.npy:", sub.shape)
 
 
+def dump_real_tile_full():
+    """BASELINE C1's input verbatim: all 58 243 rows of data-sample/sample_575.npy ((N,4) f64 x,y,z,label, UTM scale),
+    stored compressed.  A data file of the reference, not code."""
+    a = np.load(os.path.join(REF, "data-sample", "sample_575.npy"))
+    assert a.shape == (58243, 4) and a.dtype == np.float64
+    np.savez_compressed(os.path.join(OUT, "ts40k_sample575_full.npz"), tile=a)
+    print("ts40k_sample575_full.npz:", a.shape)
+
+
 def dump_loss():
     """Losses and gradients of the reference's own criterion classes (core/criterions/geneo_loss.py) on small
     (pred, gt) pairs: GENEO_Loss, GENEO_Tversky_Loss, GENEO_Dice_Loss, plus WeightedMSE.get_weight_target and
@@ -429,12 +438,16 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["loss"]:
         dump_loss()
         sys.exit(0)
+    if sys.argv[1:] == ["tile"]:
+        dump_real_tile_full()
+        sys.exit(0)
     if sys.argv[1:] == ["vxg"]:
         dump_vxg_to_xyz()
         sys.exit(0)
     dump_loss()
     dump_loss_extra()
     dump_real_tile_subset()
+    dump_real_tile_full()
     dump_vxg_to_xyz()
     dump_voxel_normalize()
     dump_kernels()

@@ -1,0 +1,147 @@
+"""The z-walk kernel over pre-folded planes (conv_occ_i8z_kernel, csrc/conv_i8z.inc) behind sn_conv_bank_prepared: the same
+contraction as sn_conv_bank (SceneNet.forward, core/models/SCENE_Net.py:322-339) with the per-bank work done once by
+sn_conv_bank_prep.  Same integers, same head: the result must equal sn_conv_bank's bit for bit on every shape, and meet
+the fp64 oracle within 1e-4.
+
+Transitivity note: at the full C2 batch the z-walk, folded, stride-4 and four-copy kernels are compared
+with each other bit for bit; the fp64 oracle is met directly at <= 2 tiles of 64^3 (seconds on the CPU), and on the full
+batch through that chain of equalities."""
+import numpy as np
+import pytest
+import torch
+
+import scene_net_amd as sna
+from scene_net_amd import _hip
+from oracle import geneo_oracle as go
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _symmetric_bank(G, seed, scale=None):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.rand((G, 9, 9, 9), generator=g) - 0.5
+    w = w + w.flip(2)
+    w = w + w.flip(3)
+    if scale is None:
+        scale = torch.logspace(-2, 0.3, G)
+    return (w * scale.view(G, 1, 1, 1)).float().contiguous()
+
+
+def _delta(before, after):
+    return tuple(a - b for a, b in zip(after, before))
+
+
+def _both(x, bank, lam, want_act=True, dt=torch.float32):
+    prep = _hip.conv_bank_prep(bank)
+    a_z, o_z = _hip.conv_bank(x, bank, lam, want_act=want_act, want_out=True, out_dtype=dt, prep=prep)
+    a_r, o_r = _hip.conv_bank(x, bank, lam, want_act=want_act, want_out=True, out_dtype=dt)
+    return (a_z, o_z), (a_r, o_r)
+
+
+@pytest.mark.parametrize("shape,G", [((2, 1, 16, 16, 64), 16), ((1, 1, 20, 18, 64), 5), ((4, 1, 32, 32, 64), 16),
+                                     ((1, 1, 64, 64, 64), 16), ((1, 1, 12, 10, 64), 33), ((1, 1, 9, 24, 128), 16),
+                                     ((3, 1, 7, 5, 16), 16), ((1, 1, 1, 1, 16), 3), ((2, 1, 40, 9, 48), 16),
+                                     ((1, 1, 128, 16, 32), 16)])
+def test_zwalk_equals_sn_conv_bank_and_oracle(hip_device, shape, G):
+    torch.manual_seed(hash((shape, G)) % 2**31)
+    occ = torch.rand(shape) < 0.3
+    bank = _symmetric_bank(G, G + shape[2])
+    lam = (torch.rand(G) - 0.3) / G
+    ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+    x, b, l = occ.to(hip_device), bank.to(hip_device), lam.to(hip_device)
+    c0 = _hip.conv_i8_path_counts()
+    (a_z, o_z), (a_r, o_r) = _both(x, b, l)
+    served, declined, routed = _delta(c0, _hip.conv_i8_path_counts())
+    groups = (G + 15) // 16
+    assert served == 2 * groups and declined == 0 and routed == 0, (served, declined, routed)
+    assert torch.equal(a_z, a_r) and torch.equal(o_z, o_r)
+    (_, only_z), (_, only_r) = _both(x, b, l, want_act=False)
+    assert torch.equal(only_z, only_r) and torch.equal(only_z, o_z)
+    (a_d, o_d), (a_dr, o_dr) = _both(x, b, l, dt=torch.float64)
+    assert torch.equal(a_d, a_dr) and torch.equal(o_d, o_dr)
+    assert (a_z.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item())
+    assert (o_z.cpu().double() - ref_out).abs().max().item() < TOL
+    assert (o_d.cpu() - ref_out).abs().max().item() < TOL
+    assert _hip.conv_i8_spin_timeouts() == 0
+
+
+def test_zwalk_full_c2_batch_and_128_cubed(hip_device):
+    """BASELINE C2's batch (32 x 64^3) and one 128^3 tile (C3/C4's grid) on the bench bank: z-walk == sn_conv_bank bit for
+    bit (which is itself equal to the stride-4 and four-copy kernels, tests/test_gpu_conv_fold.py)."""
+    from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile
+    specs, names, lambdas, last = synthetic_bank_spec()
+    model = sna.SceneNet({"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9))
+    apply_bank_spec(model, specs, names, lambdas, last)
+    model = model.to(hip_device)
+    bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+    tiles = [synthetic_tile(i, 100_000)[0] for i in range(32)]
+    occ = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles, device=hip_device), (64,) * 3, occ_dtype=torch.bool).occ
+    c0 = _hip.conv_i8_path_counts()
+    (_, o_z), (_, o_r) = _both(occ, bank, lam, want_act=False)
+    assert _delta(c0, _hip.conv_i8_path_counts()) == (2, 0, 0)
+    assert torch.equal(o_z, o_r)
+    assert float(o_z.max()) > 0.05     # not a trivial all-zero comparison
+    occ128 = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles[:2], device=hip_device), (128,) * 3,
+                                occ_dtype=torch.bool).occ
+    (a_z, o_z), (a_r, o_r) = _both(occ128, bank, lam, want_act=True)
+    assert torch.equal(o_z, o_r) and torch.equal(a_z, a_r)
+    assert _hip.conv_i8_spin_timeouts() == 0
+
+
+def test_zwalk_asymmetric_bank_runs_the_unfolded_body_in_the_same_launch(hip_device):
+    torch.manual_seed(5)
+    occ = torch.rand((2, 1, 16, 16, 64)) < 0.4
+    bank = _symmetric_bank(16, 77)
+    v = bank[7, 4, 8, 3]
+    bank[7, 4, 8, 3] = torch.nextafter(v, v + 1)
+    lam = (torch.rand(16) - 0.3) / 16
+    x, b, l = occ.to(hip_device), bank.to(hip_device), lam.to(hip_device)
+    c0 = _hip.conv_i8_path_counts()
+    (a_z, o_z), (a_r, o_r) = _both(x, b, l)
+    assert _delta(c0, _hip.conv_i8_path_counts()) == (0, 2, 0)
+    assert torch.equal(a_z, a_r) and torch.equal(o_z, o_r)
+    ref = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    assert (a_z.cpu().double() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+
+
+def test_zwalk_guard_routes_a_wide_bank_to_fp32(hip_device):
+    """a bank whose worst-case quantisation bound exceeds the tolerance: the blob's own route flag sends the launch to the
+    fp32 kernel enqueued behind it -- the same bits as the fp32 kernel called directly"""
+    torch.manual_seed(6)
+    occ = torch.rand((1, 1, 16, 16, 64)) < 0.5
+    bank = _symmetric_bank(16, 3, scale=torch.full((16,), 40.0))
+    lam = (torch.rand(16) - 0.3) / 16
+    x, b, l = occ.to(hip_device), bank.to(hip_device), lam.to(hip_device)
+    c0 = _hip.conv_i8_path_counts()
+    prep = _hip.conv_bank_prep(b)
+    a_z, o_z = _hip.conv_bank(x, b, l, want_act=True, want_out=True, prep=prep)
+    assert _delta(c0, _hip.conv_i8_path_counts()) == (0, 0, 1)
+    a_f, o_f = _hip.conv_bank(x.view(torch.uint8), b, l, want_act=True, want_out=True)   # u8: the fp32 kernel
+    assert torch.equal(a_z, a_f) and torch.equal(o_z, o_f)
+    # the same blob, tolerance off: the int8 path serves it
+    _hip.set_option("conv_i8_tolerance_ppb", 0)
+    try:
+        a_i, o_i = _hip.conv_bank(x, b, l, want_act=True, want_out=True, prep=prep)
+        a_r, o_r = _hip.conv_bank(x, b, l, want_act=True, want_out=True)
+    finally:
+        _hip.set_option("conv_i8_tolerance_ppb", 90000)
+    assert torch.equal(a_i, a_r) and torch.equal(o_i, o_r)
+
+
+def test_prep_blob_is_reusable_and_bank_specific(hip_device):
+    torch.manual_seed(9)
+    occ = (torch.rand((2, 1, 24, 16, 64)) < 0.2).to(hip_device)
+    b1, b2 = _symmetric_bank(16, 1).to(hip_device), _symmetric_bank(16, 2).to(hip_device)
+    lam = ((torch.rand(16) - 0.3) / 16).to(hip_device)
+    prep = _hip.conv_bank_prep(b1)
+    o1 = _hip.conv_bank(occ, b1, lam, prep=prep)[1]
+    o1b = _hip.conv_bank(occ, b1, lam, prep=prep)[1]
+    assert torch.equal(o1, o1b) and torch.equal(o1, _hip.conv_bank(occ, b1, lam)[1])
+    _hip.conv_bank_prep(b2, prep)                      # the same memory, re-prepared for another bank
+    o2 = _hip.conv_bank(occ, b2, lam, prep=prep)[1]
+    assert torch.equal(o2, _hip.conv_bank(occ, b2, lam)[1]) and not torch.equal(o1, o2)
+    # float / non-9^3 inputs are forwarded to sn_conv_bank untouched
+    xf = occ.float()
+    assert torch.equal(_hip.conv_bank(xf, b1, lam, prep=prep)[1], _hip.conv_bank(xf, b1, lam)[1])

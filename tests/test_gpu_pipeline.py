@@ -82,6 +82,28 @@ def test_fused_pipeline_matches_reference_chain(hip_device, golden_dir):
         assert (out[b].double().cpu() - ref[0]).abs().max().item() < TOL
 
 
+def test_c1_chain_on_the_full_reference_tile(hip_device, golden_dir):
+    """BASELINE C1 end to end: data-sample/sample_575.npy verbatim (58 243 points, UTM) -> 64^3 -> 4 GENEO kernels
+    (cy 2, cone 1, neg 1; 9^3) -> head, against the oracle chain (occupancy bit-exact, activations < 1e-4)."""
+    torch.manual_seed(575)
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_full.npz"))["tile"]
+    xyz, labels = a[:, :3], a[:, 3]
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    pipe = sna.ScenePipeline(model, (64, 64, 64), keep_labels=[15])
+    batch = sna.PointBatch.from_tiles([xyz], [labels], device=hip_device)
+    out, grids = pipe(batch, want_gt=True)
+    vox, gt = vo.voxelization_call((xyz, labels), [15], None, (64, 64, 64))
+    x = torch.from_numpy(vo.to_full_dense(vox))[None]
+    assert np.array_equal(grids.occ[0].cpu().numpy(), x[0].numpy().astype(np.float32))
+    assert np.array_equal(grids.gt_occ[0].cpu().numpy(), vo.to_full_dense(gt).astype(np.float32))
+    ref, act_ref = _oracle_forward(model, x)
+    assert (out[0].double().cpu() - ref[0]).abs().max().item() < TOL
+    # the 4-kernel contraction with its activations (int8 path on the bool grid), not only the head
+    out2, act = model(grids.occ.bool(), return_bank_activations=True)
+    assert (act[0].double().cpu() - act_ref[0]).abs().max().item() < TOL
+    assert (out2[0].double().cpu() - ref[0]).abs().max().item() < TOL
+
+
 def test_v1_module_and_wrappers(hip_device, golden_dir):
     """SCENE_Net (v1), SCENENetQuantile, SCENE_Net_Class: golden forward of the reference's v1 module."""
     import json

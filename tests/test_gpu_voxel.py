@@ -50,6 +50,19 @@ def test_real_ts40k_tile_utm_coordinates(hip_device, golden_dir):
         _check_tile(g, 0, xyz, labels, dims, [15])
 
 
+def test_c1_full_tile_64cubed(hip_device, golden_dir):
+    """BASELINE C1's input verbatim (all 58 243 rows of sample_575.npy) at the configuration BASELINE names: bbox, every
+    fp64 edge, counts, density, ratio and both occupancy planes bit-exact vs the oracle, counting and LDS-bitmap paths"""
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_full.npz"))["tile"]
+    xyz, labels = a[:, :3], a[:, 3]
+    batch = sna.PointBatch.from_tiles([xyz], [labels], device=hip_device)
+    g = sna.voxelize_batch(batch, (64, 64, 64), [15], want_density=True, want_gt=True, want_occ=True, want_gt_occ=True)
+    _check_tile(g, 0, xyz, labels, (64, 64, 64), [15])
+    assert int(g.counts[0].sum().item()) == 58243
+    go1 = sna.voxelize_batch(batch, (64, 64, 64), [15], want_occ=True, want_gt_occ=True, occ_dtype=torch.bool)
+    _check_tile(go1, 0, xyz, labels, (64, 64, 64), [15])
+
+
 def test_ragged_batch_of_synthetic_tiles(hip_device):
     sizes = [20_001, 36_076, 1, 2, 3, 58_243, 117_111, 64]  # odd/even offsets exercise the 16-byte peel
     tiles, labels = zip(*[synthetic_tile(t, max(n, 3))[0:2] for t, n in enumerate(sizes)])

@@ -15,6 +15,27 @@ def real_tile(golden_dir):
     return a[:, :3], a[:, 3]
 
 
+@pytest.fixture(scope="module")
+def c1_tile(golden_dir):
+    """BASELINE C1's input verbatim: all of the reference's data-sample/sample_575.npy (make_golden.py tile)."""
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_full.npz"))["tile"]
+    assert a.shape == (58243, 4)
+    return a[:, :3], a[:, 3]
+
+
+def test_c1_full_tile_counts_and_groupby_shape(c1_tile):
+    """the whole C1 tile at 64^3 (real UTM coordinates, |y| ~ 4.6e6): every point lands in exactly one voxel, tower
+    counts match the label column, and the bincount form equals the reference's groupby/iterrows loop shape"""
+    xyz, labels = c1_tile
+    counts, towers, g = vo.voxel_counts(xyz, (64, 64, 64), None, labels, [15])
+    assert counts.sum() == 58243 and towers.sum() == (labels == 15).sum() and (towers <= counts).all()
+    assert np.array_equal(vo.hist_on_voxel(xyz), vo.hist_on_voxel_groupby(xyz))
+    # the subset fixture is drawn from this tile and keeps its bbox-defining points: same grid geometry
+    sub = np.load(os.path.join(os.path.dirname(__file__), "golden", "ts40k_sample575_subset.npy"))
+    g2 = vo.voxelgrid_compute(sub[:, :3], n_xyz=(64, 64, 64))
+    assert np.array_equal(g["xyzmin"], g2["xyzmin"]) and np.array_equal(g["xyzmax"], g2["xyzmax"])
+
+
 def test_linspace_edges_are_numpy_linspace():
     rng = np.random.default_rng(0)
     for _ in range(200):

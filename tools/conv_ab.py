@@ -39,11 +39,16 @@ def main():
         occ = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles, device=dev), (args.grid,) * 3,
                                  occ_dtype=torch.bool).occ
 
+    prep = _hip.conv_bank_prep(bank)
+    use_prep = [False]
+
     def run(n):
         for _ in range(n):
-            _hip.conv_bank(occ, bank, lam, want_act=False, want_out=True)
+            _hip.conv_bank(occ, bank, lam, want_act=False, want_out=True, prep=prep if use_prep[0] else None)
 
     variants = {
+        "zwalk+guard": dict(legacy=0, tol=90000, fold=1, prep=True),
+        "zwalk noguard": dict(legacy=0, tol=0, fold=1, prep=True),
         "folded+guard": dict(legacy=0, tol=90000, fold=1),
         "folded noguard": dict(legacy=0, tol=0, fold=1),
         "stride4+guard": dict(legacy=0, tol=90000, fold=0),
@@ -64,6 +69,7 @@ def main():
             _hip.set_option("conv_i8_legacy", v["legacy"])
             _hip.set_option("conv_i8_tolerance_ppb", v["tol"])
             _hip.set_option("conv_i8_fold", v["fold"])
+            use_prep[0] = bool(v.get("prep"))
             run(5)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
