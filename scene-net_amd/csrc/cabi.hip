@@ -16,6 +16,8 @@ static std::atomic<int> g_skip_empty{0};
 int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8_legacy{0};
 int option_conv_i8_legacy() { return g_i8_legacy.load(std::memory_order_relaxed); }
+static std::atomic<int> g_i8z_variant{2};
+int option_conv_i8z_variant() { return g_i8z_variant.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8_fold{1};
 int option_conv_i8_fold() { return g_i8_fold.load(std::memory_order_relaxed); }
 
@@ -91,6 +93,11 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_i8_fold.store(value ? 1 : 0, std::memory_order_relaxed);
         return SN_OK;
     }
+    if (strcmp(name, "conv_i8z_variant") == 0) {
+        if (value < 0 || value > 3) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: conv_i8z_variant is 0 .. 3");
+        sn::g_i8z_variant.store(value, std::memory_order_relaxed);
+        return SN_OK;
+    }
     return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: unknown option '%s'", name);
 }
 
@@ -99,6 +106,7 @@ extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_i8_tolerance_ppb") == 0) return sn::g_i8_tol_ppb.load(std::memory_order_relaxed);
     if (name && strcmp(name, "conv_i8_legacy") == 0) return sn::option_conv_i8_legacy();
     if (name && strcmp(name, "conv_i8_fold") == 0) return sn::option_conv_i8_fold();
+    if (name && strcmp(name, "conv_i8z_variant") == 0) return sn::option_conv_i8z_variant();
     return -1;
 }
 

@@ -27,6 +27,7 @@ inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_
 
 int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 int option_conv_i8_fold();            // cabi.hip (sn_set_option "conv_i8_fold", default 1): 0 = never try the folded int8 kernel (conv_i8s.hip)
+int option_conv_i8z_variant();        // cabi.hip (sn_set_option "conv_i8z_variant"): shape of the z-walk kernel's rounds (conv_i8z.inc)
 int option_conv_i8_legacy();          // cabi.hip (sn_set_option "conv_i8_legacy"): 1 = the four-copy kernel of conv_i8.hip for every shape
 
 // hipFuncAttributeMaxDynamicSharedMemorySize, set once per kernel (and raised when a launch needs more): the

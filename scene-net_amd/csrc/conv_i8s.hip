@@ -1622,16 +1622,28 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     const size_t lds_z = lds_bytes_zwalk(), lds_4 = lds_bytes(s4);
     const size_t lds = lds_z > lds_4 ? lds_z : lds_4;
     if (lds > (size_t)kMaxLds) return 1;
-#define SN_LAUNCH_I8Z(OT)                                                                                        \
+#define SN_LAUNCH_I8Z(OT, KH, KR, KW)                                                                            \
     do {                                                                                                         \
-        auto kern = conv_occ_i8z_kernel<OT>;                                                                     \
+        auto kern = conv_occ_i8z_kernel<OT, KH, KR, KW>;                                                         \
         if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
             return check_launch("sn_conv_bank_prepared(i8z: hipFuncSetAttribute)");                              \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, x, bank, lambdas, (const uint8_t*)prep, z, s4, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, stream, x, bank, lambdas, (const uint8_t*)prep, z, s4, \
                            (OT*)act, (OT*)out);                                                                  \
     } while (0)
-    if (out_dtype == SN_F32) SN_LAUNCH_I8Z(float);
-    else SN_LAUNCH_I8Z(double);
+#define SN_LAUNCH_I8Z_V(KH, KR, KW)                                                                              \
+    do {                                                                                                         \
+        if (out_dtype == SN_F32) SN_LAUNCH_I8Z(float, KH, KR, KW);                                               \
+        else SN_LAUNCH_I8Z(double, KH, KR, KW);                                                                  \
+    } while (0)
+    // the shape of a ticket: rounds of two x-rows on 8 waves (2 per SIMD, the tile kernels' round), or rounds of one
+    // x-row -- half the accumulator registers -- on 12 waves (3 per SIMD), one, two or four of them per ticket
+    switch (sn::option_conv_i8z_variant()) {
+        case 0: SN_LAUNCH_I8Z_V(2, 1, 8); break;
+        case 1: SN_LAUNCH_I8Z_V(1, 1, 12); break;
+        case 3: SN_LAUNCH_I8Z_V(1, 4, 12); break;
+        default: SN_LAUNCH_I8Z_V(1, 2, 12); break;
+    }
+#undef SN_LAUNCH_I8Z_V
 #undef SN_LAUNCH_I8Z
     if (int rc = check_launch("sn_conv_bank_prepared(i8z)")) return rc;
     if (z.tol > 0.0f) {

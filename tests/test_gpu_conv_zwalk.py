@@ -28,6 +28,15 @@ def _symmetric_bank(G, seed, scale=None):
     return (w * scale.view(G, 1, 1, 1)).float().contiguous()
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=["2rows_8waves", "1row_12waves", "1rowx2_12waves", "1rowx4_12waves"], autouse=True)
+def zwalk_variant(request):
+    """every test runs on the four shapes of the walk's rounds (sn_set_option "conv_i8z_variant")"""
+    default = _hip.get_option("conv_i8z_variant")
+    _hip.set_option("conv_i8z_variant", request.param)
+    yield request.param
+    _hip.set_option("conv_i8z_variant", default)
+
+
 def _delta(before, after):
     return tuple(a - b for a, b in zip(after, before))
 

@@ -47,8 +47,11 @@ def main():
             _hip.conv_bank(occ, bank, lam, want_act=False, want_out=True, prep=prep if use_prep[0] else None)
 
     variants = {
-        "zwalk+guard": dict(legacy=0, tol=90000, fold=1, prep=True),
-        "zwalk noguard": dict(legacy=0, tol=0, fold=1, prep=True),
+        "zwalk 2x1x8+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=0),
+        "zwalk 1x1x12+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=1),
+        "zwalk 1x2x12+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=2),
+        "zwalk 1x4x12+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=3),
+        "zwalk 1x2x12 noguard": dict(legacy=0, tol=0, fold=1, prep=True, zv=2),
         "folded+guard": dict(legacy=0, tol=90000, fold=1),
         "folded noguard": dict(legacy=0, tol=0, fold=1),
         "stride4+guard": dict(legacy=0, tol=90000, fold=0),
@@ -70,6 +73,8 @@ def main():
             _hip.set_option("conv_i8_tolerance_ppb", v["tol"])
             _hip.set_option("conv_i8_fold", v["fold"])
             use_prep[0] = bool(v.get("prep"))
+            if "zv" in v:
+                _hip.set_option("conv_i8z_variant", v["zv"])
             run(5)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
