@@ -17,7 +17,7 @@ OBJS    := $(SOURCES:%=$(OBJDIR)/%.o)
 
 all: $(OUT)/libscenenet_hip.so
 
-$(OBJDIR)/%.o: $(SRC)/%.hip $(SRC)/common.h include/scenenet_hip.h $(wildcard $(SRC)/*.inc)
+$(OBJDIR)/%.o: $(SRC)/%.hip $(SRC)/common.h include/scenenet_hip.h $(wildcard $(SRC)/*.inc) $(SRC)/conv_prep.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(CXXFLAGS) $(FLAGS_$*) -c $< -o $@
 

@@ -194,18 +194,20 @@ def main():
     conv_ev, vox_ev = [], []
 
     def step(timed):
+        # K2 (GENEO bank + the int8 contraction's per-bank preparation, ONE launch) is forked onto a side stream: it reads
+        # only the model's scalars, so it runs beside K1 and is joined in front of K3' (scene-net_amd/pipeline.py)
+        bank, lam, prep, join = pipe.bank_beside(dev)
         if timed:
             a, b, c = ev(), ev(), ev()
             a.record()
         grids = pipe.voxelize(batch)
         if timed:
             b.record()
-        bank = model.compute_bank(dev)
-        lam = model.effective_lambdas(dev)
+        join()
         if timed:
             c0 = ev()
             c0.record()
-        _, out = sna._hip.conv_bank(grids.occ, bank, lam, want_act=False, want_out=True)
+        _, out = sna._hip.conv_bank(grids.occ, bank, lam, want_act=False, want_out=True, prep=prep)
         if timed:
             c.record()
             vox_ev.append((a, b))
@@ -303,6 +305,7 @@ def main():
     # rows x 1 1/4 dwords -> 4 steps.  `achieved` keeps SURVEY 8d's dense convention (2 * V * 729 * 16 flops per tile).
     served_now = sna._hip.conv_i8_path_counts()[0]
     folded = stride4 and tuple(KERNEL_SIZE) == (9, 9, 9) and served_now - served_before >= args.steps
+    zwalk = folded   # the step calls sn_conv_bank_prepared: the folded contraction runs as the z-walk kernel (conv_i8z.inc)
     if folded:
         i8_steps = 4
     elif stride4:
@@ -413,7 +416,8 @@ def main():
         g_ms = (time.perf_counter() - ts) / args.steps * 1e3
         graph_info = {"ms_per_step": g_ms, "tiles_per_s_per_gpu": B / (g_ms * 1e-3),
                       "identical_output": bool(torch.equal(out_graph, out)),
-                      "note": "whole step (4 voxel launches, bank, conv) replayed from one hipGraph"}
+                      "note": "whole step (4 voxel launches; bank + preparation on a parallel branch; conv) replayed "
+                              "from one hipGraph"}
         del graph
         if fused_info is not None:   # the 0.12 ms fused step is at the edge of being host bound when launched eagerly
             with torch.cuda.stream(side):
@@ -486,14 +490,16 @@ def main():
         # dominant kernel.  `achieved` = ALGORITHMIC flops (2*V*729*16 per tile) / launch time; `peak` = dense int8
         # MFMA peak.  `executed` counts what the kernel really issues (3 digit planes x 64-slot steps): that is the
         # matrix-pipe utilisation figure.
-        "roofline": {"kernel": ("conv_occ_i8f_kernel" if folded else "conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel")
+        "roofline": {"kernel": ("conv_occ_i8z_kernel" if zwalk else "conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel")
                                + " (K3', v_mfma_i32_16x16x64_i8)",
-                     "algorithm": ("bank symmetric in x and y (checked on the device per call): 9x5x5 folded taps, the same "
-                                   "integer sums as the 729-tap contraction" if folded else "729 taps per kernel"),
+                     "algorithm": ("bank symmetric in x and y (verdict of the device-side preparation, per call): 9x5x5 folded "
+                                   "taps, the same integer sums as the 729-tap contraction; z-walk over planes y-folded once "
+                                   "per column" if folded else "729 taps per kernel"),
                      "bound": "mfma", "mfma_steps_per_16x16_outputs": i8_steps,
                      "achieved": conv_tflops, "peak": PEAK_I8_MFMA_TOPS, "unit": "TFLOP/s",
                      "frac": conv_tflops / PEAK_I8_MFMA_TOPS,
-                     "traffic": traffic.get("conv_occ_i8f_kernel" if folded and "conv_occ_i8f_kernel" in traffic
+                     "traffic": traffic.get("conv_occ_i8z_kernel" if zwalk and "conv_occ_i8z_kernel" in traffic
+                                            else "conv_occ_i8f_kernel" if folded and "conv_occ_i8f_kernel" in traffic
                                             else "conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel"),
                      "launch_ms": conv_ms, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops, "executed": executed_tops,
                      "executed_frac": executed_tops / PEAK_I8_MFMA_TOPS,

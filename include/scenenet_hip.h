@@ -116,6 +116,14 @@ int sn_effective_lambdas(float* lambdas, const int32_t* order, int G, int last, 
 int sn_geneo_bank_lambdas(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
                           int32_t* status, float* lambdas, const int32_t* order, int last, float* lambdas_out,
                           sn_stream_t stream);
+/* sn_geneo_bank_lambdas (lambdas nullable: then sn_geneo_bank) and sn_conv_bank_prep in ONE launch, for 9 x 9 x 9 kernels:
+ * the workgroup that has just built kernel g prepares it for the int8 contraction from LDS (symmetry verdict, fixed-point
+ * weights, error bound, digit-table entries; see sn_conv_bank_prep below).  prep: SN_CONV_PREP_BYTES x ceil(G / 16),
+ * 16-byte aligned.  Neither the bank nor the blob depends on the voxel grid: the launch can run on a side stream next to
+ * the voxelisation and be joined in front of sn_conv_bank_prepared. */
+int sn_geneo_bank_prep(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                       int32_t* status, float* lambdas, const int32_t* order, int last, float* lambdas_out,
+                       void* prep, sn_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * K3  GENEO bank convolution + convex-combination head

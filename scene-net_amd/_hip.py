@@ -35,6 +35,7 @@ SYMBOLS = {
     "sn_geneo_bank": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_effective_lambdas": (c_int, [_P, _P, _I, _I, _P, _P]),
     "sn_conv_bank": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_geneo_bank_prep": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "sn_conv_bank_prep": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "sn_conv_bank_prepared": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sn_conv_i8_spin_timeouts": (c_int, [_P]),
@@ -241,6 +242,29 @@ def geneo_bank_lambdas(params: torch.Tensor, kinds: torch.Tensor, kernel_size: S
                                       _ptr(order, torch.int32, "order"), int(last), _ptr(lam), _stream())
     _check(rc, "sn_geneo_bank_lambdas")
     return bank, lam
+
+
+@_on_tensor_device
+def geneo_bank_prep(params: torch.Tensor, kinds: torch.Tensor, lambdas: Optional[torch.Tensor] = None,
+                    order: Optional[torch.Tensor] = None, last: int = 0, bank: Optional[torch.Tensor] = None,
+                    lam_out: Optional[torch.Tensor] = None, prep: Optional[torch.Tensor] = None):
+    """sn_geneo_bank_prep: the 9 x 9 x 9 bank, (optionally) the effective coefficients, and the int8 contraction's
+    preparation blob in ONE launch -> (bank [G,9,9,9] f32, lam [G] f32 | None, prep uint8).  `bank`, `lam_out`, `prep`:
+    caller-owned outputs to write into (persistent buffers: nothing is allocated on the step)."""
+    G = params.shape[0]
+    if bank is None:
+        bank = torch.empty((G, 9, 9, 9), dtype=torch.float32, device=params.device)
+    nbytes = SN_CONV_PREP_BYTES * ((G + 15) // 16)
+    if prep is None:
+        prep = torch.empty(nbytes, dtype=torch.uint8, device=params.device)
+    if lambdas is not None and lam_out is None:
+        lam_out = torch.empty(G, dtype=torch.float32, device=params.device)
+    rc = load().sn_geneo_bank_prep(_ptr(params, torch.float32, "params"), _ptr(kinds, torch.int32, "kinds"), G, 9, 9, 9,
+                                   _ptr(bank, torch.float32, "bank"), None, _ptr(lambdas, torch.float32, "lambdas"),
+                                   _ptr(order, torch.int32, "order"), int(last), _ptr(lam_out, torch.float32, "lam_out"),
+                                   _ptr(prep, torch.uint8, "prep"), _stream())
+    _check(rc, "sn_geneo_bank_prep")
+    return bank, (lam_out if lambdas is not None else None), prep
 
 
 @_on_tensor_device

@@ -10,6 +10,8 @@
 
 namespace {
 
+#include "conv_prep.h"   // prep_one_kernel: the int8 contraction's per-bank preparation, run as this kernel's tail
+
 constexpr int kThreads = 256;
 constexpr float kEps = 1e-8f;        // default `epsilon` of the v2 gaussians
 constexpr float kPi = 3.14159274f;   // torch.pi rounded to fp32 by the fp32 multiply
@@ -45,20 +47,34 @@ __device__ void effective_lambdas_thread(float* __restrict__ lambdas, const int3
     lambdas[last] = eff;
 }
 
-// grid G (+ 1 when the effective coefficients ride along: sn_geneo_bank_lambdas; that extra workgroup does them)
+// grid G (+ 1 when the effective coefficients ride along: sn_geneo_bank_lambdas; that extra workgroup does them).
+// kPrep (sn_geneo_bank_prep, 9 x 9 x 9 kernels): grid 16 ceil(G / 16) (+ 1); every workgroup g < 16 ceil(G / 16) also
+// prepares kernel g for the int8 contraction (conv_prep.h) from the weights it has just built, still in LDS --
+// workgroups G .. write the zero entries of the last group of 16.
+template <bool kPrep>
 __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __restrict__ params,
                                                               const int32_t* __restrict__ kinds, int kz, int kx,
                                                               int ky, float* __restrict__ bank,
                                                               int32_t* __restrict__ status, int G,
                                                               float* __restrict__ lambdas,
                                                               const int32_t* __restrict__ order, int last,
-                                                              float* __restrict__ lambdas_out) {
+                                                              float* __restrict__ lambdas_out,
+                                                              uint8_t* __restrict__ prep) {
     extern __shared__ float lds[];
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
-    if (g >= G) {
+    const int ngeneo = kPrep ? 16 * ((G + 15) / 16) : G;
+    if (g >= ngeneo) {
         if (tid == 0 && lambdas) effective_lambdas_thread(lambdas, order, G, last, lambdas_out);
         return;
+    }
+    if constexpr (kPrep) {
+        if (g >= G) {   // a pad entry of the last group of 16: all-zero kernel
+            for (int i = tid; i < 729; i += kThreads) lds[i] = 0.0f;
+            prep_one_kernel(lds, reinterpret_cast<int*>(lds + 732), false, g & 15, prep + (size_t)(g >> 4) * SN_CONV_PREP_BYTES,
+                            tid);
+            return;
+        }
     }
     const int nfloor = kx * ky;
     const int vol = kz * nfloor;
@@ -140,8 +156,12 @@ __global__ __launch_bounds__(kThreads) void geneo_bank_kernel(const float* __res
             mean = seg_sum[0] / (float)vol + neg;  // sum_zero(.) - neg_factor, neg_sphere.py:151
         else
             mean = seg_sum[idx / nfloor] / (float)nfloor;  // sum_zero, cylinder.py:81-82
-        out[idx] = vals[idx] - mean;
+        const float wv = vals[idx] - mean;
+        out[idx] = wv;
+        if constexpr (kPrep) vals[idx] = wv;   // (each thread rewrites only what it read: the means are in seg_sum)
     }
+    if constexpr (kPrep)   // vol == 729 (checked by the host); seg_sum is dead after the loop's barrier inside
+        prep_one_kernel(vals, reinterpret_cast<int*>(seg_sum + kz), true, g & 15, prep + (size_t)(g >> 4) * SN_CONV_PREP_BYTES, tid);
 }
 
 __global__ void effective_lambdas_kernel(float* __restrict__ lambdas, const int32_t* __restrict__ order, int G,
@@ -169,8 +189,8 @@ extern "C" int sn_geneo_bank(const float* params, const int32_t* kinds, int G, i
     const long vol = (long)kz * kx * ky;
     if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank: kernel volume %ld > 12000", vol);
     size_t lds = (size_t)(vol + kz + 1) * sizeof(float);
-    hipLaunchKernelGGL(geneo_bank_kernel, dim3(G), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz, kx,
-                       ky, bank, status, G, (float*)nullptr, (const int32_t*)nullptr, 0, (float*)nullptr);
+    hipLaunchKernelGGL(geneo_bank_kernel<false>, dim3(G), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz, kx,
+                       ky, bank, status, G, (float*)nullptr, (const int32_t*)nullptr, 0, (float*)nullptr, (uint8_t*)nullptr);
     return sn::check_launch("sn_geneo_bank");
 }
 
@@ -184,7 +204,25 @@ extern "C" int sn_geneo_bank_lambdas(const float* params, const int32_t* kinds, 
     const long vol = (long)kz * kx * ky;
     if (vol > 12000) return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank_lambdas: kernel volume %ld > 12000", vol);
     size_t lds = (size_t)(vol + kz + 1) * sizeof(float);
-    hipLaunchKernelGGL(geneo_bank_kernel, dim3(G + 1), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz,
-                       kx, ky, bank, status, G, lambdas, order, last, lambdas_out);
+    hipLaunchKernelGGL(geneo_bank_kernel<false>, dim3(G + 1), dim3(kThreads), lds, sn::as_stream(stream), params, kinds, kz,
+                       kx, ky, bank, status, G, lambdas, order, last, lambdas_out, (uint8_t*)nullptr);
     return sn::check_launch("sn_geneo_bank_lambdas");
+}
+
+extern "C" int sn_geneo_bank_prep(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                                  int32_t* status, float* lambdas, const int32_t* order, int last, float* lambdas_out,
+                                  void* prep, sn_stream_t stream) {
+    if (!params || !kinds || !bank || !prep) return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank_prep: null pointer");
+    if (lambdas && (!order || !lambdas_out)) return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank_prep: lambdas without order / out");
+    if (G <= 0 || (lambdas && (last < 0 || last >= G))) return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank_prep: bad G / last");
+    if (kz != 9 || kx != 9 || ky != 9)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_geneo_bank_prep: the prepared contraction serves 9 x 9 x 9 kernels (got %d,%d,%d)", kz,
+                        kx, ky);
+    if (reinterpret_cast<uintptr_t>(prep) & 15) return sn::fail(SN_ERR_INVALID_ARG, "sn_geneo_bank_prep: prep must be 16-byte aligned");
+    const size_t lds = (size_t)(729 + kz + 1 + 8) * sizeof(float);
+    const int ngeneo = 16 * ((G + 15) / 16);
+    hipLaunchKernelGGL(geneo_bank_kernel<true>, dim3(ngeneo + (lambdas ? 1 : 0)), dim3(kThreads), lds, sn::as_stream(stream),
+                       params, kinds, kz, kx, ky, bank, status, G, lambdas, order, last, lambdas_out,
+                       static_cast<uint8_t*>(prep));
+    return sn::check_launch("sn_geneo_bank_prep");
 }

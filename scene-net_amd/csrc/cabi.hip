@@ -14,12 +14,55 @@ char* error_buffer() {
 }
 static std::atomic<int> g_skip_empty{0};
 int option_conv_skip_empty_tiles() { return g_skip_empty.load(std::memory_order_relaxed); }
-static std::atomic<int> g_i8_legacy{0};
-int option_conv_i8_legacy() { return g_i8_legacy.load(std::memory_order_relaxed); }
+static std::atomic<int> g_i8_legacy{-1};   // -1: not looked at yet; SN_CONV_I8_LEGACY=1 in the environment starts it at 1
+int option_conv_i8_legacy() {
+    int v = g_i8_legacy.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SN_CONV_I8_LEGACY");
+        int expected = -1;
+        g_i8_legacy.compare_exchange_strong(expected, (e && e[0] == '1') ? 1 : 0, std::memory_order_relaxed);
+        v = g_i8_legacy.load(std::memory_order_relaxed);
+    }
+    return v;
+}
 static std::atomic<int> g_i8z_variant{2};
 int option_conv_i8z_variant() { return g_i8z_variant.load(std::memory_order_relaxed); }
-static std::atomic<int> g_i8_fold{1};
-int option_conv_i8_fold() { return g_i8_fold.load(std::memory_order_relaxed); }
+static std::atomic<int> g_i8_fold{-1};   // -1: not looked at yet; SN_CONV_I8_NOFOLD=1 in the environment starts it at 0
+int option_conv_i8_fold() {
+    int v = g_i8_fold.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SN_CONV_I8_NOFOLD");
+        int expected = -1;
+        g_i8_fold.compare_exchange_strong(expected, (e && e[0] == '1') ? 0 : 1, std::memory_order_relaxed);
+        v = g_i8_fold.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+
+
+namespace {
+struct ExtraOpt {
+    const char* name;
+    const char* env;
+    std::atomic<int> value;   // -1: not looked at yet (the environment decides at first use)
+};
+ExtraOpt g_extra[kOptCount] = {{"conv_no_i8", "SN_CONV_NO_I8", {-1}},
+                               {"conv_double_buffer", "SN_CONV_DOUBLE_BUFFER", {-1}},
+                               {"conv_lin_no24", "SN_CONV_LIN_NO24", {-1}},
+                               {"conv_i8_no_stage", "SN_CONV_I8_NO_STAGE", {-1}}};
+}  // namespace
+int option_extra(ExtraOption which) {
+    ExtraOpt& o = g_extra[which];
+    int v = o.value.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv(o.env);
+        v = (e && e[0] == '1') ? 1 : 0;
+        int expected = -1;
+        o.value.compare_exchange_strong(expected, v, std::memory_order_relaxed);
+        v = o.value.load(std::memory_order_relaxed);
+    }
+    return v;
+}
 
 static thread_local Gate g_gate{{nullptr, nullptr, nullptr}, {0, 0, 0}};
 Gate current_gate() { return g_gate; }
@@ -98,6 +141,11 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_i8z_variant.store(value, std::memory_order_relaxed);
         return SN_OK;
     }
+    for (auto& o : sn::g_extra)
+        if (strcmp(name, o.name) == 0) {
+            o.value.store(value ? 1 : 0, std::memory_order_relaxed);
+            return SN_OK;
+        }
     return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: unknown option '%s'", name);
 }
 
@@ -107,6 +155,9 @@ extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_i8_legacy") == 0) return sn::option_conv_i8_legacy();
     if (name && strcmp(name, "conv_i8_fold") == 0) return sn::option_conv_i8_fold();
     if (name && strcmp(name, "conv_i8z_variant") == 0) return sn::option_conv_i8z_variant();
+    if (name)
+        for (int i = 0; i < sn::kOptCount; ++i)
+            if (strcmp(name, sn::g_extra[i].name) == 0) return sn::option_extra((sn::ExtraOption)i);
     return -1;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include "scenenet_hip.h"
 
 namespace sn {
@@ -57,6 +58,29 @@ struct GateScope {
   private:
     int slot_;
 };
+
+// Result-preserving switches beside the named accessors above: set with sn_set_option(name, v); the environment variable
+// listed with each is read ONCE, the first time the option is looked at (never per call: a getenv per launch sat on the
+// production dispatch, and a stray variable could change kernels mid-run).
+enum ExtraOption {
+    kOptConvNoI8 = 0,        // "conv_no_i8"        SN_CONV_NO_I8=1         binary occupancy through the fp32 kernel
+    kOptConvDoubleBuffer,    // "conv_double_buffer" SN_CONV_DOUBLE_BUFFER=1 fp32 kernel: double-buffered 4x4x64 tiles
+    kOptConvLinNo24,         // "conv_lin_no24"     SN_CONV_LIN_NO24=1      K3L: 32-byte instead of 24-byte kernel rows
+    kOptConvI8NoStage,       // "conv_i8_no_stage"  SN_CONV_I8_NO_STAGE=1   four-copy kernel without the LDS-DMA staging
+    kOptCount
+};
+int option_extra(ExtraOption which);   // cabi.hip
+// Wrong-result timing switches (a skipped epilogue, idle waves ...) exist only in builds made with -DSN_CONV_DEBUG
+// (make EXTRA=-DSN_CONV_DEBUG): in the product they read as 0 whatever the environment says.
+inline int debug_env_int(const char* name) {
+#ifdef SN_CONV_DEBUG
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 
 float option_conv_i8_tolerance();   // cabi.hip (sn_set_option "conv_i8_tolerance_ppb"): 0 = quantisation guard off
 // One int of device memory per call, out of a per-device ring allocated once (1024 calls may be in flight before a

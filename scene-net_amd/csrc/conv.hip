@@ -444,11 +444,9 @@ int sn::conv_bank_group(const void* x, int x_dtype, const float* bank, const flo
 
     if (x_dtype == SN_OCC8) {
         // binary occupancy bytes: int8 matrix cores (exact integer accumulation of 24-bit fixed-point weights)
-        const char* no_i8 = getenv("SN_CONV_NO_I8");
-        if (!(no_i8 && no_i8[0] == '1')) {
+        if (!sn::option_extra(sn::kOptConvNoI8)) {
             // ky = 9: the stride-4 kernel (one halo copy, 12 MFMA steps); everything else: the four-copy kernel
-            const char* legacy = getenv("SN_CONV_I8_LEGACY");
-            if (!sn::option_conv_i8_legacy() && !(legacy && legacy[0] == '1')) {
+            if (!sn::option_conv_i8_legacy()) {
                 const int rs = sn::conv_occ_i8s((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky,
                                                 act, out, out_dtype, sn::as_stream(stream));
                 if (rs <= 0) return rs;
@@ -476,8 +474,7 @@ int sn::conv_bank_group(const void* x, int x_dtype, const float* bank, const flo
     // wave's epilogue overlaps its SIMD partner's MFMAs) runs 127.7 TF; the double-buffered 4x4x64 tile (1 round
     // per wave per barrier: epilogues and halo hand-over of all waves coincide) 118.5 TF.  Double buffering is
     // therefore opt-in (SN_CONV_DOUBLE_BUFFER=1) until its tile can hold more rounds.
-    const char* force = getenv("SN_CONV_DOUBLE_BUFFER");
-    if (force && force[0] == '1') {
+    if (sn::option_extra(sn::kOptConvDoubleBuffer)) {
         for (const auto& c : cand) {
             set_tile(s, c[0], c[1]);
             const int rows = (s.TZ + kz - 1) * (s.TX + kx - 1);

@@ -701,10 +701,9 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
     s.PYA = (py + 3) & ~3;
     s.delta = s.PYA - py;
     s.nyt = (Y + TY - 1) / TY;
-    const char* dbg = getenv("SN_CONV_I8_DBG");
-    s.dbg = dbg ? atoi(dbg) : 0;
+    s.dbg = sn::debug_env_int("SN_CONV_I8_DBG");   // (0 in the product: common.h)
     s.skip_empty = sn::option_conv_skip_empty_tiles();
-    const char* nostage = getenv("SN_CONV_I8_NO_STAGE");
+    const bool nostage = sn::option_extra(sn::kOptConvI8NoStage) != 0;
     const int cus = num_cus();
     const int need = s.delta + 15 + 48 + 4 * s.C + 3;  // bytes of a halo row the reads can touch
     // variants in order of preference: (row stride, LDS-DMA staging)
@@ -714,7 +713,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
         const int ypb = var[0];
         const bool stage = var[1] != 0;
         if (need > ypb) continue;
-        if (stage && nostage && nostage[0] == '1') continue;
+        if (stage && nostage) continue;
         bool found = false;
         for (const auto& c : cand) {
             s.TZ = c[0]; s.TX = c[1];

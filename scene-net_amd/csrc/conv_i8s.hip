@@ -39,6 +39,8 @@
 
 namespace {
 
+#include "conv_prep.h"
+
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 // relu(tanh(v)): 0 for v <= 0, else 1 - 2 / (exp(2v) + 1) on the hardware exp / rcp (abs. error ~2e-7, inside the 1e-4
@@ -63,7 +65,6 @@ constexpr int kNB = 3;          // halo ring
 constexpr int kMaxRQ = 24;      // kernel rows per lane group (kz * kx <= 96)
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kSpinMax = 1 << 22;
-constexpr double kQMax = 8355711.0;
 
 // which kernel rows (dz, dx) lane group q carries, in what order (host-built: plan_rows)
 struct RowPlan {
@@ -78,8 +79,7 @@ struct RowPlan {
 #ifndef SN_I8F_AHEAD
 #define SN_I8F_AHEAD 2
 #endif
-constexpr int kFoldSteps = 4, kFoldRows = 3, kFoldSlots = kFoldSteps * kFoldRows;
-constexpr bool fold_slot_single(int st, int j) { return j == 2 && st < 3; }
+// (kFoldSteps, kFoldRows, kFoldSlots, fold_slot_*: conv_prep.h)
 struct FoldPlan {
     short h1[4][kFoldSlots];    // halo row index dz * XP + dx'
     short h2[4][kFoldSlots];    // halo row index dz * XP + 8 - dx'   (single slots: unused)
@@ -209,10 +209,6 @@ __device__ __forceinline__ bool wave_wait(const int* c, int expect) {
 
 // 4x4 byte transpose: o[r] = (a.byte r, b.byte r, c.byte r, d.byte r)
 __device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t (&o)[4]) {
-#ifdef SN_I8S_NOALIGN
-    o[0] = a; o[1] = b; o[2] = c; o[3] = d;
-    return;
-#endif
     const uint32_t p0 = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a0 b0 a1 b1
     const uint32_t p1 = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a2 b2 a3 b3
     const uint32_t q0 = __builtin_amdgcn_perm(d, c, 0x05010400u);   // c0 d0 c1 d1
@@ -237,11 +233,7 @@ __device__ __forceinline__ void transpose3(uint32_t a, uint32_t b, uint32_t c, u
 template <int R>
 __device__ __forceinline__ uint32_t window(uint32_t hi, uint32_t lo) {   // bytes R .. R+3 of (hi : lo)
     if constexpr (R == 0) return lo;
-#ifdef SN_I8S_NOALIGN   // timing experiment (wrong results): how much of the launch is the v_alignbyte / v_perm issue slots
-    else return lo;
-#else
     else return __builtin_amdgcn_alignbyte(hi, lo, R);
-#endif
 }
 
 // fp32 bank -> LDS, coalesced, one batch of loads; the first two tiles' halos are requested while those loads fly (the
@@ -316,62 +308,6 @@ __device__ __forceinline__ void quantise_kernels(const Shape& s, int ntaps, floa
     }
 }
 
-// one kernel's part of quantise_kernels_folded on the 32 lanes of a half wave (l32): `w` = the kernel's 729 fp32 weights in
-// LDS (overwritten by Q at the unique taps); shared with the stand-alone preparation kernel (conv_i8z.inc), so that both
-// produce the same bits
-__device__ __forceinline__ void quantise_folded_half(float* w, bool valid, int l32, float& scale_out, double& bnd_out,
-                                                     double& pos_out, double& neg_out) {
-    constexpr int nuniq = 9 * 5 * 5;
-    auto tap_of = [](int u, int& mult) -> int {   // u = (dz * 5 + dx) * 5 + dy, dx, dy <= 4
-        const int dy = u % 5, r = u / 5, dx = r % 5, dz = r / 5;
-        mult = (dx < 4 ? 2 : 1) * (dy < 4 ? 2 : 1);
-        return (dz * 9 + dx) * 9 + dy;
-    };
-    float m = 0.0f;
-    if (valid)
-        for (int u = l32; u < nuniq; u += 32) {
-            int mult;
-            const float a = fabsf(w[tap_of(u, mult)]);
-            m = (a <= 3.0e38f) ? fmaxf(m, a) : __int_as_float(0x7fc00000);
-        }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        const float u = __shfl_xor(m, o, 64);
-        m = (m != m || u != u) ? __int_as_float(0x7fc00000) : fmaxf(m, u);
-    }
-    const double S = (m > 0.0f) ? kQMax / (double)m : 0.0;
-    const double invS = (double)m / kQMax;
-    double ep = 0.0, en = 0.0, qp = 0.0, qn = 0.0;
-    if (valid)
-        for (int u = l32; u < nuniq; u += 32) {
-            int mult;
-            const int t = tap_of(u, mult);
-            if (m > 0.0f) {
-                const double wv = (double)w[t];
-                const int Q = __double2int_rn(wv * S);
-                const double e = ((double)Q * invS - wv) * (double)mult;
-                ep += e > 0.0 ? e : 0.0;
-                en += e < 0.0 ? -e : 0.0;
-                qp += Q > 0 ? (double)Q * (double)mult : 0.0;   // (exact: |Q| < 2^23, 729 taps)
-                qn += Q < 0 ? -(double)Q * (double)mult : 0.0;
-                w[t] = __int_as_float(Q);
-            } else {
-                w[t] = 0.0f;   // all-zero or poisoned kernel: Q = 0 (scale carries a NaN)
-            }
-        }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        ep += __shfl_xor(ep, o, 64);
-        en += __shfl_xor(en, o, 64);
-        qp += __shfl_xor(qp, o, 64);
-        qn += __shfl_xor(qn, o, 64);
-    }
-    scale_out = (m != m) ? m : (float)((double)m / kQMax);
-    bnd_out = ep > en ? ep : en;
-    pos_out = qp;
-    neg_out = qn;
-}
-
 // quantise_kernels for a bank that is symmetric in x and y (the folded kernel, after its symmetry check): only the 9 x 5 x 5
 // unique taps are visited, each standing for 1, 2 or 4 equal weights -- the same maximum, the same error sums up to the
 // order of the fp64 additions, and Q written where the folded table build reads it (dx <= 4, dy <= 4).
@@ -408,11 +344,7 @@ __device__ __forceinline__ void finish_round(const SH& s, const TileCoord& c, in
                                              const float* lamhi, OT* __restrict__ act, OT* __restrict__ out, size_t V) {
     const int gz = c.z0 + lz;
     if (gz >= s.Z) return;
-#ifdef SN_I8F_NOEPI
-    if (true) {
-#else
     if (s.dbg & 1) {
-#endif
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -1001,11 +933,6 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
 //     q * (2 kXP 96) + (a kXP + dx') 96        (lane group q carries planes dz = 2 q + a, a = 0, 1),
 // one per-lane register plus an immediate of the LDS read -- no offset table, no address arithmetic in the rounds.  The two
 // irregular slots (8: the single of plane 8 and three pads; 11: plane 8's doubles) take their offsets from the plan.
-constexpr int fold_slot_a(int slot) { return slot >= 5 && slot != 8 && slot != 11 ? 1 : 0; }   // slots 0..4: a = 0; 5, 6, 7, 9, 10: a = 1
-constexpr int fold_slot_dx(int slot) {
-    return slot == 2 || slot == 5 ? 4 : slot == 0 || slot == 6 ? 0 : slot == 1 || slot == 7 ? 1 : slot == 3 || slot == 9 ? 2 : 3;
-}
-constexpr bool fold_slot_irregular(int slot) { return slot == 8 || slot == 11; }
 
 template <typename OT, int kXP>
 __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* __restrict__ x,
@@ -1198,14 +1125,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
                                         : ((uint64_t)r[1] << 32 | r[0]) + ((uint64_t)r[4] << 32 | r[3]);
             const uint32_t R0 = (uint32_t)R01, R1 = (uint32_t)(R01 >> 32);
             const uint32_t R2 = single ? r[2] : r[2] + r[5];
-#ifdef SN_I8F_NOFOLD   // timing experiment (wrong results): the round without the y fold
-            X[0][J] = (int)R0; X[1][J] = (int)R1; X[2][J] = (int)R2; X[3][J] = (int)R0;
-#else
             X[0][J] = (int)(R0 + __builtin_amdgcn_perm(R2, R1, 0x01020304u));
             X[1][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 1) + __builtin_amdgcn_perm(R2, R1, 0x02030405u));
             X[2][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 2) + __builtin_amdgcn_perm(R2, R1, 0x03040506u));
             X[3][J] = (int)(__builtin_amdgcn_alignbyte(R1, R0, 3) + __builtin_amdgcn_perm(R2, R1, 0x04050607u));
-#endif
             centre = R1;
         };
         auto centres = [&](uint32_t c0, uint32_t c1, uint32_t c2, i32x4 (&X)[4]) {
@@ -1292,11 +1215,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             auto mma_tile = [&](const i32x4 (&w)[3], const i32x4& xv, int v, bool first) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-#ifdef SN_I8F_NOMMA   // timing experiment (wrong results): the round without its MFMAs
-                    acc[d][v] = first ? (w[d] ^ xv) : (acc[d][v] ^ xv);
-#else
                     acc[d][v] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], xv, first ? i32x4{0, 0, 0, 0} : acc[d][v], 0, 0, 0);
-#endif
             };
             auto mma_step = [&](const i32x4 (&w)[3], const i32x4 (&X)[2][4], bool first, auto&& work) {
                 auto group = [&](auto VC) {   // (compile-time v: the pieces index registers, never memory)
@@ -1483,12 +1402,10 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
     s.gate = sn::current_gate();
     s.nyt = (Y + TY - 1) / TY;
-    const char* dbg = getenv("SN_CONV_I8_DBG");
-    s.dbg = dbg ? atoi(dbg) : 0;
-    const char* stg = getenv("SN_CONV_I8S_STAGGER");
-    s.stagger = stg ? atoi(stg) : 0;   // x 64 clocks; [measured] 100 (about half a round) vs 0: 0.2045 vs 0.2039 ms -- rounds are claimed, the waves spread by themselves
-    const char* stat = getenv("SN_CONV_I8S_STATIC");
-    s.dynamic = !(stat && stat[0] == '1');
+    // wrong-result / timing switches: -DSN_CONV_DEBUG builds only (common.h); 0 in the product
+    s.dbg = sn::debug_env_int("SN_CONV_I8_DBG");
+    s.stagger = sn::debug_env_int("SN_CONV_I8S_STAGGER");   // x 64 clocks; [measured] 100 (about half a round) vs 0: 0.2045 vs 0.2039 ms -- rounds are claimed, the waves spread by themselves
+    s.dynamic = !sn::debug_env_int("SN_CONV_I8S_STATIC");
     const int cus = num_cus();
     const bool found = plan_stride4(s, B, Z, X, Y, kz, kx, cus);
     if (!found) return 1;
@@ -1497,9 +1414,8 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     const int grid = cus < s.ntiles ? cus : s.ntiles;
     // 1. the folded kernel (banks symmetric in x and y: every GENEO bank) -- it checks the symmetry on the device, runs the
     //    stride-4 body itself for a bank that is not, and leaves *flag = 0 (served) or 1 (bound exceeded: fp32 kernel)
-    const char* nofold = getenv("SN_CONV_I8_NOFOLD");
     int32_t* flag = sn::device_flag_slot();
-    const bool fold = kz == 9 && kx == 9 && flag && !(nofold && nofold[0] == '1') && sn::option_conv_i8_fold() &&
+    const bool fold = kz == 9 && kx == 9 && flag && sn::option_conv_i8_fold() &&
                       s.dbg == 0;   // (the debug switches belong to the stride-4 kernel)
     bool folded = false;
     if (fold) {

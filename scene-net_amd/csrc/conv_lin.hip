@@ -545,8 +545,7 @@ bool lin_plan(int B, int Z, int X, int Y, int G, int kz, int kx, int ky, LinShap
     s.ntiles = (int)nt;
     s.npairs = kz * kx;
     // 24-byte packing of the kernel rows when a strip's window fits 24 halo bytes (ky <= 9 with PYA == py)
-    const char* no24 = getenv("SN_CONV_LIN_NO24");
-    w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !(no24 && no24[0] == '1');
+    w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !sn::option_extra(sn::kOptConvLinNo24);
     s.nsteps = w24 ? (3 * s.npairs + 7) / 8 : (s.npairs + 1) / 2;   // odd counts end with a lone step after the pairs
     s.XP = TX + kx - 1;
     s.rows = (TZ + kz - 1) * s.XP;
@@ -578,7 +577,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     s.gate = sn::current_gate();
     int grid = num_cus();
     if (grid > s.ntiles) grid = s.ntiles;
-    s.dbg = getenv("SN_CONV_LIN_DBG") ? atoi(getenv("SN_CONV_LIN_DBG")) : 0;
+    s.dbg = sn::debug_env_int("SN_CONV_LIN_DBG");   // (0 in the product: common.h)
     s.tol = sn::option_conv_i8_tolerance();
     if (out_dtype == SN_BF16) s.tol = 0.0f;   // bf16 storage rounds at 2^-9: the 24-bit fixed point is not what limits it
     s.route = nullptr;

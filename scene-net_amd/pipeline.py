@@ -53,19 +53,57 @@ class ScenePipeline:
     """
 
     def __init__(self, model: SceneNet, voxelgrid_dims: Sequence[int] = (64, 64, 64),
-                 keep_labels: Optional[Sequence[float]] = None):
+                 keep_labels: Optional[Sequence[float]] = None, overlap_bank: bool = True):
         self.model = model
         self.voxelgrid_dims = tuple(int(v) for v in voxelgrid_dims)
         self.keep_labels = keep_labels
+        # K2 (bank builder + the contraction's preparation) reads only the model's scalars: it runs on a forked stream
+        # beside K1 and is joined in front of K3 (a parallel branch when the pass is captured into a hipGraph)
+        self.overlap_bank = bool(overlap_bank)
+        self._side = None
 
     def voxelize(self, batch: PointBatch, want_gt: bool = False) -> VoxelGrids:
         # binary occupancy as torch.bool: 1 byte/voxel between K1 and K3, and K3 runs on the int8 matrix cores
         return voxelize_batch(batch, self.voxelgrid_dims, self.keep_labels, want_occ=True, want_gt_occ=want_gt,
                               occ_dtype=torch.bool)
 
+    def bank_beside(self, device):
+        """Starts K2 on the side stream: returns (bank, lam, prep | None, join) -- call join() on the main stream before
+        the contraction.  The fork waits for everything enqueued so far (the previous pass's contraction still reads the
+        model's bank / prep buffers), so K2 of pass i+1 overlaps K1 of pass i+1, not K3 of pass i."""
+        model = self.model
+        main = torch.cuda.current_stream(device)
+        if self._side is None or self._side.device != main.device:
+            self._side = torch.cuda.Stream(device=device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if model.kernel_size_of_bank() == (9, 9, 9):
+                bank, prep = model.compute_bank_prepared(device)
+            else:
+                bank, prep = model.compute_bank(device), None
+                bank.record_stream(main)
+            lam = model.effective_lambdas(device)
+        return bank, lam, prep, (lambda: main.wait_stream(side))
+
     def __call__(self, batch: PointBatch, want_gt: bool = False):
-        grids = self.voxelize(batch, want_gt)
-        out = self.model(grids.occ)
+        model = self.model
+        plain = not (torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()))
+        if not (self.overlap_bank and plain):
+            grids = self.voxelize(batch, want_gt)
+            out = model(grids.occ)
+            return (out, grids) if want_gt else out
+        # inference: the module's own no-grad forward (scene_net.py), with K2 forked beside K1
+        with torch.no_grad():
+            dev = batch.pts.device
+            bank, lam, prep, join = self.bank_beside(dev)
+            grids = self.voxelize(batch, want_gt)
+            join()
+            x = grids.occ
+            if model.fused_forward and _hip.conv_fused_supported(x, model.kernel_size_of_bank()):
+                out = _hip.conv_fused(x, bank, lam, out_dtype=model.activation_dtype or torch.float32)
+            else:
+                out = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True, prep=prep)[1]
         return (out, grids) if want_gt else out
 
     def capture(self, batch: PointBatch, want_gt: bool = False) -> "CapturedPipeline":

@@ -242,6 +242,28 @@ class SceneNet(nn.Module):
         params, kinds = self.packed_params(device)
         return _hip.geneo_bank(params, kinds, self.kernel_size_of_bank())
 
+    def compute_bank_prepared(self, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(bank [G,9,9,9] f32, prep uint8): compute_bank and the int8 contraction's per-bank preparation in ONE launch
+        (sn_geneo_bank_prep), written into two buffers the model keeps per device -- nothing is allocated per call, so
+        the launch can sit on a side stream next to the voxelisation (ScenePipeline).  9 x 9 x 9 kernels only.  The
+        reference rebuilds its kernels at every forward (SCENE_Net.py:322-327); so does this."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.kernel_size_of_bank() != (9, 9, 9):
+            raise _hip.HipLibraryError("compute_bank_prepared serves 9 x 9 x 9 kernels")
+        params, kinds = self.packed_params(device)
+        G = params.shape[0]
+        bufs = self.__dict__.get("_prepared_bufs")
+        if bufs is None or bufs[0].device != device or bufs[0].shape[0] != G:
+            bufs = (torch.empty((G, 9, 9, 9), dtype=torch.float32, device=device),
+                    torch.zeros(_hip.SN_CONV_PREP_BYTES * ((G + 15) // 16), dtype=torch.uint8, device=device))
+            self.__dict__["_prepared_bufs"] = bufs
+        bank, _, prep = _hip.geneo_bank_prep(params, kinds, bank=bufs[0], prep=bufs[1])
+        return bank, prep
+
+    def serves_prepared(self, x: torch.Tensor) -> bool:
+        """binary occupancy and a 9 x 9 x 9 bank: the z-walk kernel behind sn_conv_bank_prepared"""
+        return x.dtype == torch.bool and x.is_cuda and self.kernel_size_of_bank() == (9, 9, 9)
+
     # ------------------------------------------------------------------ differentiable host logic (training)
     def _leaf_slots(self):
         """[(nn.Parameter, slot)]: GENEO g's parameters at g*SN_NPARAM + slot, coefficient g at G*SN_NPARAM + g."""
@@ -329,8 +351,11 @@ class SceneNet(nn.Module):
                     # what the reference feeds is f64 {0., 1.} (ToFullDense): a device-side check routes such grids
                     # to the int8 kernels and anything else to the fp32 contraction, without a host sync
                     return _hip.forward_auto(x.contiguous(), bank, lam)[0]
+            prep = None
+            if self.serves_prepared(x):   # the per-bank work of the int8 contraction once, fused into the bank builder
+                bank, prep = self.compute_bank_prepared(x.device)
             act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
-                                      out_dtype=out_dtype)
+                                      out_dtype=out_dtype, prep=prep)
         return (out, act) if return_bank_activations else out
 
 

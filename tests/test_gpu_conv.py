@@ -375,7 +375,7 @@ def test_fused_linear_against_oracle_and_dense_kernel(hip_device, shape, ks, G):
 
 @pytest.mark.parametrize("shape,ks", [((2, 1, 24, 40, 64), (9, 9, 9)), ((1, 1, 16, 20, 72), (5, 3, 7)),
                                       ((3, 1, 9, 17, 128), (9, 5, 5)), ((1, 1, 8, 16, 64), (3, 9, 2))])
-def test_fused_linear_row_packings_are_bit_identical(hip_device, monkeypatch, shape, ks):
+def test_fused_linear_row_packings_are_bit_identical(hip_device, shape, ks):
     """The 24-byte packing of the kernel rows (ky <= 9) and the 32-byte one accumulate the same integers."""
     torch.manual_seed(11)
     G = 5
@@ -383,9 +383,11 @@ def test_fused_linear_row_packings_are_bit_identical(hip_device, monkeypatch, sh
     bank = (_rand_bank(G, ks, 3, "cpu") * torch.logspace(-1, 0.3, G).view(G, 1, 1, 1)).to(hip_device).contiguous()
     lam = ((torch.rand(G) - 0.4) / G).to(hip_device)
     packed = _hip.conv_fused(x, bank, lam)
-    monkeypatch.setenv("SN_CONV_LIN_NO24", "1")
-    wide = _hip.conv_fused(x, bank, lam)
-    monkeypatch.delenv("SN_CONV_LIN_NO24")
+    _hip.set_option("conv_lin_no24", 1)   # (an option now: the environment is read once, never per call)
+    try:
+        wide = _hip.conv_fused(x, bank, lam)
+    finally:
+        _hip.set_option("conv_lin_no24", 0)
     assert torch.equal(packed, wide)
 
 

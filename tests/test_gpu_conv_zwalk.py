@@ -154,3 +154,54 @@ def test_prep_blob_is_reusable_and_bank_specific(hip_device):
     # float / non-9^3 inputs are forwarded to sn_conv_bank untouched
     xf = occ.float()
     assert torch.equal(_hip.conv_bank(xf, b1, lam, prep=prep)[1], _hip.conv_bank(xf, b1, lam)[1])
+
+
+def _bench_model(hip_device, geneo_num=None):
+    from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec
+    geneo_num = geneo_num or {"cy": 6, "cone": 5, "neg": 5}
+    specs, names, lambdas, last = synthetic_bank_spec(geneo_num)
+    model = sna.SceneNet(geneo_num, (9, 9, 9))
+    apply_bank_spec(model, specs, names, lambdas, last)
+    return model.to(hip_device)
+
+
+@pytest.mark.parametrize("geneo_num", [{"cy": 6, "cone": 5, "neg": 5}, {"cy": 2, "cone": 1, "neg": 1},
+                                       {"cy": 7, "cone": 6, "neg": 7}])
+def test_bank_builder_prepares_what_the_standalone_preparation_does(hip_device, geneo_num):
+    """sn_geneo_bank_prep (K2 with the preparation as its tail) == sn_geneo_bank followed by sn_conv_bank_prep: the same bank
+    bits, and the same blob in every field a kernel reads (G = 16, G = 4 with twelve zero pad entries, G = 20: two groups)."""
+    model = _bench_model(hip_device, geneo_num)
+    bank = model.compute_bank(hip_device)
+    bank_p, prep_p = model.compute_bank_prepared(hip_device)
+    assert torch.equal(bank, bank_p)
+    prep = _hip.conv_bank_prep(bank)
+    G = bank.shape[0]
+    for grp in range((G + 15) // 16):
+        a = prep_p[grp * _hip.SN_CONV_PREP_BYTES:(grp + 1) * _hip.SN_CONV_PREP_BYTES].cpu().numpy()
+        b = prep[grp * _hip.SN_CONV_PREP_BYTES:(grp + 1) * _hip.SN_CONV_PREP_BYTES].cpu().numpy()
+        for name, lo, hi in [("digit table", 0, 12288), ("scales", 12288, 12352), ("bounds", 12352, 12480),
+                             ("symmetry", 12480, 12544), ("fit", 12544, 12608), ("magic", 12608, 12612)]:
+            assert np.array_equal(a[lo:hi], b[lo:hi]), (grp, name)
+        sym = a[12480:12544].view(np.int32)
+        assert sym.tolist() == [1] * 16          # every GENEO family is symmetric in x and y, bit for bit; pads too
+
+
+def test_pipeline_with_the_bank_forked_beside_the_voxelisation(hip_device):
+    """ScenePipeline(overlap_bank=True): K2 on a side stream next to K1, joined before K3 -- the same bits as the serial
+    pass, for the 16-kernel contraction and for the forward through linearity, eagerly and replayed from a hipGraph."""
+    from scene_net_amd.synthetic import synthetic_tile
+    model = _bench_model(hip_device)
+    tiles = [synthetic_tile(i, 50_000)[0] for i in range(4)]
+    batch = sna.PointBatch.from_tiles(tiles, device=hip_device)
+    for fused in (False, True):
+        model.fused_forward = fused
+        with torch.no_grad():
+            serial = sna.ScenePipeline(model, (64, 64, 64), overlap_bank=False)(batch)
+            pipe = sna.ScenePipeline(model, (64, 64, 64), overlap_bank=True)
+            forked = [pipe(batch) for _ in range(3)]
+            cap = pipe.capture(batch)
+            replayed = cap.replay().clone()
+        assert all(torch.equal(serial, f) for f in forked)
+        assert torch.equal(serial, replayed)
+    model.fused_forward = True
+    assert _hip.conv_i8_spin_timeouts() == 0
