@@ -65,6 +65,11 @@ enum {
 };
 
 int sn_version(void);
+/* Allocates the current device's pool of flag / ticket words (20 KB) now -- the only allocation the library ever makes.
+ * Optional: the first int8 launch on a device does it too, but that launch must then not be inside a stream capture
+ * (hipMalloc / hipMemset are illegal there).  Launches made while their stream is capturing draw words that are never
+ * handed out again, so a captured graph owns its flags (see csrc/cabi.hip). */
+int sn_prepare_device(void);
 /* Diagnostics: how many sn_conv_bank launches (this device, this process) the folded int8 kernel served [0], declined
  * because the bank was not symmetric in x and y [1], and handed to the fp32 kernel because the quantisation bound
  * exceeded the tolerance [2].  Synchronises the device.  (No reference counterpart.) */
@@ -296,6 +301,20 @@ int sn_voxel_occupancy_fused(const double* pts, const double* labels, const int6
                              double* bbox, double* desc, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
                              int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
                              sn_stream_t stream);
+
+/* sn_voxel_occupancy_fused in VOXEL-SIZE mode (voxelize_ply with size_x / size_y / size_z, utils/pcd_processing.py:365-367;
+ * the mode SemanticKITTI uses, core/datasets/semKITTI.py:453-455): every tile's grid extents follow from its own bounding
+ * box -- computed on the device as in sn_voxel_desc_sized, no host round trip -- and the binary grids are written padded
+ * to the maximum (nx, ny, nz): dims [B,3] i32 = each tile's own (n_x, n_y, n_z), status [B] i32 (nullable) = 1 where a
+ * tile needs more than the maximum (its points beyond are dropped), voxels beyond a tile's own dims are 0.  Same
+ * LDS-bitmap kernels (no global atomic per point), same workspaces and outputs as sn_voxel_occupancy_fused; the
+ * "count > column minimum" rule of ToFullDense(normalize_xyz(.)) is evaluated over each tile's OWN part of the grid. */
+int sn_voxel_occupancy_sized(const double* pts, const double* labels, const int64_t* offsets, int B,
+                             const double* size_xyz_host, int nx, int ny, int nz,
+                             const double* keep_labels_host, int n_keep, double* partial_ws, double* bbox,
+                             double* desc, int32_t* dims, int32_t* status, uint32_t* bits_ws, void* occ,
+                             void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                             int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream);
 
 /* Grid -> points: out[c, i] = grid[b(i), c, vz, vx, vy] for every point i of the batch, binned exactly as the
  * scatter binned it (same desc); points outside the edge table get `fill`.  grid [B,channels,nz,nx,ny] and

@@ -27,6 +27,7 @@ SN_NPARAM = 8
 _P, _I = c_void_p, c_int
 SYMBOLS = {
     "sn_version": (c_int, []),
+    "sn_prepare_device": (c_int, []),
     "sn_last_error": (c_char_p, []),
     "sn_device_count": (c_int, []),
     "sn_conv_i8_path_counts": (c_int, [_P]),
@@ -52,6 +53,8 @@ SYMBOLS = {
     "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "sn_voxel_occupancy_fused": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
                                          _P]),
+    "sn_voxel_occupancy_sized": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P,
+                                         _P, _P, _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
     "sn_grid_to_points": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -556,6 +559,43 @@ def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, kee
                                          _stream())
     _check(rc, "sn_voxel_occupancy_fused")
     return occ, gt_occ, flags, dropped, desc, bbox
+
+
+@_on_tensor_device
+def voxel_occupancy_sized(pts, labels, offsets, size_xyz: Sequence[float], n_xyz_max, keep_labels: Sequence[float] = (),
+                          want_gt_occ: bool = False, out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True):
+    """sn_voxel_occupancy_sized: voxel-size mode on the LDS-bitmap kernels.  Returns
+    (occ, gt_occ | None, flags, dropped, desc, dims [B,3], status [B], bbox [B,6])."""
+    B = offsets.numel() - 1
+    nx, ny, nz = (int(v) for v in n_xyz_max)
+    V = nx * ny * nz
+    dev = pts.device
+    planes = 2 if want_gt_occ else 1
+    partial = torch.empty((B, SN_BBOX_PARTS, 6), dtype=torch.float64, device=dev)
+    desc = torch.empty((B, desc_len(nx, ny, nz)), dtype=torch.float64, device=dev)
+    bbox = torch.empty((B, 6), dtype=torch.float64, device=dev)
+    dims = torch.empty((B, 3), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    bits = torch.empty((B * SN_OCC_PARTS * (planes * (V // 32) + 1),), dtype=torch.int32, device=dev)
+    occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev)
+    gt_occ = torch.empty((B, 1, nz, nx, ny), dtype=out_dtype, device=dev) if want_gt_occ else None
+    flags = torch.empty((B,), dtype=torch.int32, device=dev)
+    dropped = torch.empty((B,), dtype=torch.int32, device=dev)
+    counts = towers = None
+    if exact_fallback:
+        counts = torch.empty((B, V), dtype=torch.int32, device=dev)
+        towers = torch.empty((B, V), dtype=torch.int32, device=dev) if want_gt_occ else None
+    keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
+    size = (ctypes.c_double * 3)(*[float(v) for v in size_xyz])
+    rc = load().sn_voxel_occupancy_sized(_ptr(pts, torch.float64, "pts"),
+                                         _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
+                                         _ptr(offsets, torch.int64, "offsets"), B, ctypes.cast(size, c_void_p), nx, ny, nz,
+                                         ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
+                                         _ptr(partial), _ptr(bbox), _ptr(desc), _ptr(dims), _ptr(status), _ptr(bits),
+                                         _ptr(occ), _ptr(gt_occ), _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped),
+                                         _ptr(counts), _ptr(towers), _stream())
+    _check(rc, "sn_voxel_occupancy_sized")
+    return occ, gt_occ, flags, dropped, desc, dims, status, bbox
 
 
 @_on_tensor_device

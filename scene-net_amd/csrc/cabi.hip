@@ -83,23 +83,43 @@ GateScope::~GateScope() {
 static std::atomic<int> g_i8_tol_ppb{90000};
 float option_conv_i8_tolerance() { return 1e-9f * (float)g_i8_tol_ppb.load(std::memory_order_relaxed); }
 
-int32_t* device_flag_slot() {
-    constexpr int kRing = 1024, kMaxDev = 16;
-    static std::mutex mu;
-    static int32_t* ring[kMaxDev] = {nullptr};
-    static unsigned next[kMaxDev] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ring[dev]) {
-        if (hipMalloc((void**)&ring[dev], kRing * sizeof(int32_t)) != hipSuccess) {
+// Flag / ticket words for the launches that need one int of device memory.  Two pools per device, allocated together
+// the first time (sn_prepare_device, or the first call -- which must then be outside a stream capture):
+//   * eager launches draw from a RING of 1024 words (a word is reused after 1024 further launches of this process on the
+//     device: the launches that share a word are on one stream in practice, and each rewrites it before reading);
+//   * a launch made while its stream is CAPTURING draws from a pool that is never recycled, so a hipGraph owns the words
+//     baked into it and no eager call on another stream ever shares one with a replay (4096 words; when they are gone
+//     captures fall back to the ring).  The prepared contraction (sn_conv_bank_prepared) needs neither: its flag lives in
+//     the caller's blob.
+namespace {
+constexpr int kFlagRing = 1024, kFlagCapture = 4096, kFlagMaxDev = 16;
+std::mutex g_flag_mu;
+int32_t* g_flag_mem[kFlagMaxDev] = {nullptr};
+unsigned g_flag_next[kFlagMaxDev] = {0}, g_flag_cap_next[kFlagMaxDev] = {0};
+int32_t* flag_pool_locked(int dev) {
+    if (!g_flag_mem[dev]) {
+        if (hipMalloc((void**)&g_flag_mem[dev], (kFlagRing + kFlagCapture) * sizeof(int32_t)) != hipSuccess) {
             (void)hipGetLastError();
-            ring[dev] = nullptr;
+            g_flag_mem[dev] = nullptr;
             return nullptr;
         }
-        (void)hipMemset(ring[dev], 0, kRing * sizeof(int32_t));
+        (void)hipMemset(g_flag_mem[dev], 0, (kFlagRing + kFlagCapture) * sizeof(int32_t));
     }
-    return ring[dev] + (next[dev]++ % kRing);
+    return g_flag_mem[dev];
+}
+}  // namespace
+
+int32_t* device_flag_slot(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kFlagMaxDev) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+    if (!capturing) (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_flag_mu);
+    int32_t* mem = flag_pool_locked(dev);
+    if (!mem) return nullptr;
+    if (capturing && g_flag_cap_next[dev] < (unsigned)kFlagCapture) return mem + kFlagRing + g_flag_cap_next[dev]++;
+    return mem + (g_flag_next[dev]++ % kFlagRing);
 }
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
@@ -161,7 +181,15 @@ extern "C" int sn_get_option(const char* name) {
     return -1;
 }
 
-extern "C" int sn_version(void) { return 100; }
+extern "C" int sn_prepare_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= sn::kFlagMaxDev)
+        return sn::fail(SN_ERR_NO_DEVICE, "sn_prepare_device: no current HIP device");
+    std::lock_guard<std::mutex> lock(sn::g_flag_mu);
+    return sn::flag_pool_locked(dev) ? SN_OK : sn::fail(SN_ERR_LAUNCH, "sn_prepare_device: cannot allocate the flag pool");
+}
+
+extern "C" int sn_version(void) { return 101; }
 
 extern "C" const char* sn_last_error(void) { return sn::error_buffer(); }
 

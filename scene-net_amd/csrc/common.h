@@ -83,8 +83,9 @@ inline int debug_env_int(const char* name) {
 }
 
 float option_conv_i8_tolerance();   // cabi.hip (sn_set_option "conv_i8_tolerance_ppb"): 0 = quantisation guard off
-// One int of device memory per call, out of a per-device ring allocated once (1024 calls may be in flight before a
-// slot is reused): the flag an int8 launch leaves for the gated fp32 launch enqueued behind it, dynamic tile tickets.
-int32_t* device_flag_slot();        // cabi.hip; nullptr if the ring cannot be allocated
+// One int of device memory per call (the flag an int8 launch leaves for the gated fp32 launch enqueued behind it, dynamic
+// tile tickets): from a recycled ring for eager launches, from a never-recycled pool while `stream` is capturing
+// (cabi.hip).  nullptr if the pool cannot be allocated.
+int32_t* device_flag_slot(hipStream_t stream);
 
 }  // namespace sn

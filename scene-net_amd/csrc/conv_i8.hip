@@ -750,7 +750,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
         // may be in flight before a slot is reused.
         int* ticket = nullptr;
         if (s.skip_empty && s.ntiles > grid) {
-            ticket = sn::device_flag_slot();
+            ticket = sn::device_flag_slot(stream);
             if (ticket && hipMemsetAsync(ticket, 0, sizeof(int), stream) != hipSuccess) {
                 (void)hipGetLastError();
                 ticket = nullptr;  // static order still gives the right answer
@@ -759,7 +759,7 @@ int conv_occ_i8(const uint8_t* x, const float* bank, const float* lambdas, int B
         s.tol = sn::option_conv_i8_tolerance();
         s.route = nullptr;
         if (s.tol > 0.0f) {
-            s.route = sn::device_flag_slot();
+            s.route = sn::device_flag_slot(stream);
             if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
         }
 #define SN_LAUNCH_I8(OT, YPBV, STG)                                                                              \

@@ -1414,7 +1414,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     const int grid = cus < s.ntiles ? cus : s.ntiles;
     // 1. the folded kernel (banks symmetric in x and y: every GENEO bank) -- it checks the symmetry on the device, runs the
     //    stride-4 body itself for a bank that is not, and leaves *flag = 0 (served) or 1 (bound exceeded: fp32 kernel)
-    int32_t* flag = sn::device_flag_slot();
+    int32_t* flag = sn::device_flag_slot(stream);
     const bool fold = kz == 9 && kx == 9 && flag && sn::option_conv_i8_fold() &&
                       s.dbg == 0;   // (the debug switches belong to the stride-4 kernel)
     bool folded = false;

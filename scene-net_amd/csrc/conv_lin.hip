@@ -582,7 +582,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     if (out_dtype == SN_BF16) s.tol = 0.0f;   // bf16 storage rounds at 2^-9: the 24-bit fixed point is not what limits it
     s.route = nullptr;
     if (s.tol > 0.0f) {
-        s.route = sn::device_flag_slot();
+        s.route = sn::device_flag_slot(stream);
         if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
     }
 #define SN_LAUNCH_LIN(OT)                                                                                         \

@@ -304,17 +304,34 @@ __device__ __forceinline__ double np_floor_divide(double a, double b) {
     if (__dsub_rn(div, fl) > 0.5) fl = __dadd_rn(fl, 1.0);
     return fl;
 }
-__global__ void desc_sized_kernel(const double* __restrict__ box, Vec3s size, int nx, int ny, int nz,
+// box: [B,6] (nparts == 0), or the per-workgroup partial boxes [B, nparts, 6] of bbox_partial_kernel (min / max are exact:
+// any order of reduction gives the same box); bbox_out (nullable): the reduced raw box.
+__global__ void desc_sized_kernel(const double* __restrict__ box, int nparts, Vec3s size, int nx, int ny, int nz,
                                   double* __restrict__ desc, int32_t* __restrict__ dims,
-                                  int32_t* __restrict__ status) {
+                                  int32_t* __restrict__ status, double* __restrict__ bbox_out) {
     const int b = blockIdx.x;
     double* d = desc + (size_t)b * SN_DESC_LEN(nx, ny, nz);
-    const double* bb = box + (size_t)b * 6;
+    __shared__ double red6[6];
+    if (nparts > 0) {
+        const double* pb = box + (size_t)b * nparts * 6;
+        if (threadIdx.x < 6) {
+            double v = (threadIdx.x < 3) ? DBL_MAX : -DBL_MAX;
+            for (int pp = 0; pp < nparts; ++pp) {
+                const double u = pb[pp * 6 + threadIdx.x];
+                v = (threadIdx.x < 3) ? fmin(v, u) : fmax(v, u);
+            }
+            red6[threadIdx.x] = v;
+        }
+    } else if (threadIdx.x < 6) {
+        red6[threadIdx.x] = box[(size_t)b * 6 + threadIdx.x];
+    }
+    __syncthreads();
+    if (bbox_out && threadIdx.x < 6) bbox_out[b * 6 + threadIdx.x] = red6[threadIdx.x];
     double lo[3], hi[3], r[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        lo[c] = bb[c];
-        hi[c] = bb[3 + c];
+        lo[c] = red6[c];
+        hi[c] = red6[3 + c];
         r[c] = __dsub_rn(hi[c], lo[c]);
     }
     const double rmax = fmax(r[0], fmax(r[1], r[2]));
@@ -638,7 +655,8 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
                                                                 OT* __restrict__ occ, OT* __restrict__ gt_occ,
                                                                 int32_t* __restrict__ flags,
                                                                 const int32_t* __restrict__ dropped_parts,
-                                                                int32_t* __restrict__ dropped) {
+                                                                int32_t* __restrict__ dropped,
+                                                                const int32_t* __restrict__ dims, int nx) {
     const int b = blockIdx.y;
     if (dropped && blockIdx.x == 0 && threadIdx.x == 0) {
         int t = 0;
@@ -651,8 +669,12 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
     // words % 64 == 0), the emptiness proof rides on the words this loop has merged anyway; otherwise a second pass
     // re-merges the words of each row.
     const int wpr = ny >> 5;   // words per row
-    const bool fused_proof = flags && (ny & 31) == 0 && wpr >= 1 && wpr <= 64 && (wpr & (wpr - 1)) == 0 &&
+    // (voxel-size mode, dims != null: the grid is padded to the maximum and only the tile's own n_z x n_x rows, n_y bits
+    // each, are the reference's grid -- the padding must not count as an empty row: second pass)
+    const bool fused_proof = flags && !dims && (ny & 31) == 0 && wpr >= 1 && wpr <= 64 && (wpr & (wpr - 1)) == 0 &&
                              (words & 63) == 0;
+    const int own_nx = dims ? dims[b * 3 + 0] : nx, own_ny = dims ? dims[b * 3 + 1] : ny,
+              own_nz = dims ? dims[b * 3 + 2] : rows / (nx > 0 ? nx : 1);
     bool empty = false;
     for (int w = gtid; w < words; w += gstride) {
         const uint32_t m0 = merged_word(src, parts, planes, words, 0, w);
@@ -668,7 +690,8 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
     if (!fused_proof) {
         // row r owns bits [r*ny, (r+1)*ny)
         for (int r = gtid; r < rows && !empty; r += gstride) {
-            const long lo = (long)r * ny, hi = lo + ny;
+            if (dims && (r / nx >= own_nz || r % nx >= own_nx)) continue;   // a padding row
+            const long lo = (long)r * ny, hi = lo + own_ny;
             uint32_t any = 0u;
             for (long w = lo >> 5; w <= (hi - 1) >> 5; ++w) {
                 uint32_t m = merged_word(src, parts, planes, words, 0, w);
@@ -696,9 +719,10 @@ __global__ __launch_bounds__(256) void occ_fallback_kernel(const double* __restr
                                                             KeepLabels keep, const int32_t* __restrict__ flags,
                                                             int32_t* __restrict__ counts_ws,
                                                             int32_t* __restrict__ towers_ws, OT* __restrict__ occ,
-                                                            OT* __restrict__ gt_occ) {
+                                                            OT* __restrict__ gt_occ, const int32_t* __restrict__ dims) {
     const int b = blockIdx.x;
     if (!flags[b]) return;
+    const int own_nx = dims ? dims[b * 3 + 0] : nx, own_ny = dims ? dims[b * 3 + 1] : ny, own_nz = dims ? dims[b * 3 + 2] : nz;
     extern __shared__ double smem[];
     const int ne = nx + ny + nz + 3;
     double* edges = smem;
@@ -726,8 +750,12 @@ __global__ __launch_bounds__(256) void occ_fallback_kernel(const double* __restr
                              }, t ? labels : nullptr);
     __threadfence();
     __syncthreads();
-    for (size_t i = threadIdx.x; i < V; i += blockDim.x)
-        atomicMin(&cmin[i % ny], __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (size_t i = threadIdx.x; i < V; i += blockDim.x) {
+        // (voxel-size mode: the column statistics are over the tile's own n_z x n_x x n_y part of the padded grid)
+        const int yy = (int)(i % ny), xx = (int)((i / ny) % nx), zz = (int)(i / ((size_t)ny * nx));
+        if (yy < own_ny && xx < own_nx && zz < own_nz)
+            atomicMin(&cmin[yy], __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     __syncthreads();
     for (size_t i = threadIdx.x; i < V; i += blockDim.x) {
         const int cnt = __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -965,8 +993,8 @@ extern "C" int sn_voxel_desc_sized(const double* bbox, int B, const double* size
         sz.v[c] = size_xyz_host[c];
         if (!(sz.v[c] > 0.0)) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_desc_sized: voxel size must be > 0");
     }
-    hipLaunchKernelGGL(desc_sized_kernel, dim3(B), dim3(128), 0, sn::as_stream(stream), bbox, sz, nx, ny, nz, desc, dims,
-                       status);
+    hipLaunchKernelGGL(desc_sized_kernel, dim3(B), dim3(128), 0, sn::as_stream(stream), bbox, 0, sz, nx, ny, nz, desc, dims,
+                       status, (double*)nullptr);
     return sn::check_launch("sn_voxel_desc_sized");
 }
 
@@ -1045,7 +1073,7 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
                           int ny, int nz, const double* keep_labels_host, int n_keep, uint32_t* bits_ws, void* occ,
                           void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped, int32_t* counts_ws,
                           int32_t* towers_ws, const double* box_parts, int nbparts, int regular, double* bbox_out,
-                          sn_stream_t stream) {
+                          sn_stream_t stream, const int32_t* dims = nullptr) {
     if (!pts || !offsets || !desc || !bits_ws || !occ)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: null pointer");
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -1097,17 +1125,17 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
     if (C > blocks_per_tile(B, 2048)) C = blocks_per_tile(B, 2048);
     if (out_dtype == SN_U8)
         hipLaunchKernelGGL(occ_finalize_kernel<uint8_t>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes,
-                           parts, rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped);
+                           parts, rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped, dims, nx);
     else
         hipLaunchKernelGGL(occ_finalize_kernel<float>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes, parts,
-                           rows, ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped);
+                           rows, ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped, dims, nx);
     // flagged tiles (a y column might be full): redone exactly by one gated launch
     if (flags && counts_ws) {
         const size_t lds3 = (size_t)ne * sizeof(double) + (size_t)ny * sizeof(int);
         if (lds3 > 64 * 1024) return sn::fail(SN_ERR_UNSUPPORTED, "sn_voxel_occupancy: edge table too large");
 #define SN_FALLBACK(OT, AL)                                                                                        \
     hipLaunchKernelGGL((occ_fallback_kernel<OT, AL>), dim3(B), dim3(256), lds3, s, pts, gt_occ ? labels : nullptr, \
-                       offsets, desc, nx, ny, nz, keep, flags, counts_ws, towers_ws, (OT*)occ, (OT*)gt_occ)
+                       offsets, desc, nx, ny, nz, keep, flags, counts_ws, towers_ws, (OT*)occ, (OT*)gt_occ, dims)
         if (out_dtype == SN_U8) { if (al) SN_FALLBACK(uint8_t, true); else SN_FALLBACK(uint8_t, false); }
         else { if (al) SN_FALLBACK(float, true); else SN_FALLBACK(float, false); }
 #undef SN_FALLBACK
@@ -1145,6 +1173,38 @@ extern "C" int sn_voxel_occupancy_fused(const double* pts, const double* labels,
     return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
                           out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
                           bbox, stream);
+}
+
+extern "C" int sn_voxel_occupancy_sized(const double* pts, const double* labels, const int64_t* offsets, int B,
+                                        const double* size_xyz_host, int nx, int ny, int nz,
+                                        const double* keep_labels_host, int n_keep, double* partial_ws, double* bbox,
+                                        double* desc, int32_t* dims, int32_t* status, uint32_t* bits_ws, void* occ,
+                                        void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                                        int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream) {
+    if (!pts || !offsets || !partial_ws || !desc || !dims || !size_xyz_host)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_sized: null pointer");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_sized: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny,
+                        nz);
+    Vec3s sz;
+    for (int c = 0; c < 3; ++c) {
+        sz.v[c] = size_xyz_host[c];
+        if (!(sz.v[c] > 0.0)) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_sized: voxel size must be > 0");
+    }
+    hipStream_t s = sn::as_stream(stream);
+    dim3 grid(SN_BBOX_PARTS, B);
+    if (aligned16(pts))
+        hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    else
+        hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    // per-tile grid extents and padded edge tables from the partial boxes, on the device (no host round trip)
+    hipLaunchKernelGGL(desc_sized_kernel, dim3(B), dim3(128), 0, s, partial_ws, SN_BBOX_PARTS, sz, nx, ny, nz, desc, dims,
+                       status, bbox);
+    if (int rc = sn::check_launch("sn_voxel_occupancy_sized(bbox, descriptor)")) return rc;
+    // the LDS-bitmap kernels run unchanged on the padded tables (a point never bins beyond its tile's own dims: the
+    // edges there are +inf); the column rule of ToFullDense(normalize_xyz(.)) looks at each tile's own part only
+    return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
+                          out_dtype, flags, dropped, counts_ws, towers_ws, nullptr, 0, 0, nullptr, stream, dims);
 }
 
 extern "C" int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets,

@@ -43,6 +43,7 @@ def launch_ranks(n: int, script: str, argv: Sequence[str], extra_env: Optional[D
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this host
+        #   (rehearsed only: no >= 2-GPU RCCL run of this launcher is on record yet -- tests/test_gpu_rccl.py)
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, script, *argv], env=env))

@@ -53,10 +53,19 @@ class ScenePipeline:
     """
 
     def __init__(self, model: SceneNet, voxelgrid_dims: Sequence[int] = (64, 64, 64),
-                 keep_labels: Optional[Sequence[float]] = None, overlap_bank: bool = True):
+                 keep_labels: Optional[Sequence[float]] = None, overlap_bank: bool = True,
+                 voxel_dims: Optional[Sequence[float]] = None, per_point: bool = False, tau: Optional[float] = None):
+        """voxel_dims (size_x, size_y, size_z): voxel-size mode (utils/pcd_processing.py:365-367, what SemanticKITTI uses,
+        core/datasets/semKITTI.py:453-455) -- `voxelgrid_dims` is then the capacity the per-scan grids are padded to.
+        per_point: the call also returns every point's prediction [1, total_points] -- the voxel it was binned into,
+        read back with the scatter's own binning (the per-point form of utils/voxelization.py:304-360: prob_to_label with
+        `tau`, vxg_to_xyz's voxel -> coordinate walk replaced by point -> voxel)."""
         self.model = model
         self.voxelgrid_dims = tuple(int(v) for v in voxelgrid_dims)
         self.keep_labels = keep_labels
+        self.voxel_dims = None if voxel_dims is None else tuple(float(v) for v in voxel_dims)
+        self.per_point = bool(per_point)
+        self.tau = tau
         # K2 (bank builder + the contraction's preparation) reads only the model's scalars: it runs on a forked stream
         # beside K1 and is joined in front of K3 (a parallel branch when the pass is captured into a hipGraph)
         self.overlap_bank = bool(overlap_bank)
@@ -65,7 +74,14 @@ class ScenePipeline:
     def voxelize(self, batch: PointBatch, want_gt: bool = False) -> VoxelGrids:
         # binary occupancy as torch.bool: 1 byte/voxel between K1 and K3, and K3 runs on the int8 matrix cores
         return voxelize_batch(batch, self.voxelgrid_dims, self.keep_labels, want_occ=True, want_gt_occ=want_gt,
-                              occ_dtype=torch.bool)
+                              occ_dtype=torch.bool, voxel_dims=self.voxel_dims)
+
+    def _finish(self, out, grids, batch, want_gt):
+        if self.per_point:
+            from .tiles import point_predictions
+            pts_pred = point_predictions(out, batch, grids, tau=self.tau)
+            return (out, grids, pts_pred) if want_gt else (out, pts_pred)
+        return (out, grids) if want_gt else out
 
     def bank_beside(self, device):
         """Starts K2 on the side stream: returns (bank, lam, prep | None, join) -- call join() on the main stream before
@@ -92,7 +108,7 @@ class ScenePipeline:
         if not (self.overlap_bank and plain):
             grids = self.voxelize(batch, want_gt)
             out = model(grids.occ)
-            return (out, grids) if want_gt else out
+            return self._finish(out, grids, batch, want_gt)
         # inference: the module's own no-grad forward (scene_net.py), with K2 forked beside K1
         with torch.no_grad():
             dev = batch.pts.device
@@ -104,7 +120,7 @@ class ScenePipeline:
                 out = _hip.conv_fused(x, bank, lam, out_dtype=model.activation_dtype or torch.float32)
             else:
                 out = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True, prep=prep)[1]
-        return (out, grids) if want_gt else out
+            return self._finish(out, grids, batch, want_gt)
 
     def capture(self, batch: PointBatch, want_gt: bool = False) -> "CapturedPipeline":
         """The whole pass over `batch` (its device buffers, as they are refilled in place later) recorded into one
@@ -127,9 +143,11 @@ class CapturedPipeline:
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
-            res = pipe(batch, want_gt)
-        self.out, self.grids = res if want_gt else (res, None)
+            self.result = pipe(batch, want_gt)
+        res = self.result if isinstance(self.result, tuple) else (self.result,)
+        self.out = res[0]
+        self.grids = res[1] if want_gt else None
 
     def replay(self):
         self.graph.replay()
-        return (self.out, self.grids) if self.grids is not None else self.out
+        return self.result

@@ -12,6 +12,11 @@ the step is TWO graphs with the one real exchange of the path between them:
     eager:   ONE all-reduce over the flat vector of the ~50 scalar gradients (RCCL over xGMI on a node)
     graph 2: optimizer.step()
 Capture uses the relaxed (thread-local) error mode, so the group's watchdog thread may keep calling into HIP.
+
+STATUS: REHEARSED ONLY.  The N > 1 form has run on two gloo ranks sharing one GPU (tests/test_gpu_ddp.py,
+tests/test_gpu_rccl.py::test_worker_rehearsed_over_gloo_on_one_gpu); it has not yet executed over RCCL on two devices --
+tests/test_gpu_rccl.py does that by itself on any box with >= 2 HIP devices.  Until such a run is on record, treat the
+two-graph step under an RCCL watchdog thread as untested.
 """
 from __future__ import annotations
 

@@ -204,3 +204,81 @@ def test_float_occupancy_grids_take_the_int8_path_on_a_device_side_check(hip_dev
     outr, flagr = _hip.forward_auto(xr, bank, lam)
     assert flagr.item() == 0
     assert (outr - _hip.conv_bank(xr, bank, lam, want_act=False, want_out=True)[1]).abs().max().item() < 1e-6
+
+
+def _kitti_like_scan(seed, n=120_000):
+    """A SemanticKITTI-shaped scan (sensor frame): ground returns thinning with range, walls, poles (label 80)."""
+    rng = np.random.default_rng(seed)
+    r = 2.0 + 48.0 * rng.random(n) ** 1.7
+    a = rng.random(n) * 2 * np.pi
+    z = -1.7 + 0.02 * r * rng.standard_normal(n)
+    wall = rng.random(n) < 0.25
+    z[wall] = -1.7 + rng.random(wall.sum()) * rng.choice([2.0, 4.0, 8.0], wall.sum())
+    pts = np.stack([r * np.cos(a), r * np.sin(a), z], axis=1)
+    labels = np.where(wall & (rng.random(n) < 0.1), 80.0, 40.0)
+    return pts, labels
+
+
+def test_c4_chain_size_mode_conv_head_per_point_gather(hip_device):
+    """BASELINE C4 as ONE call: 4 Velodyne-shaped scans -> voxel-size mode at a 128^3 capacity (pcd_processing.py:365-367,
+    semKITTI.py:453-455) -> GENEO bank conv + head -> per-point read-back, against the oracle chain on each scan's OWN grid
+    (voxel_oracle -> geneo_oracle.scenenet_forward -> index by the oracle's voxel ids).  The padded part of our grid is
+    zero, which is exactly the zero padding of conv3d(padding='same') on the scan's own grid."""
+    torch.manual_seed(44)
+    scans, labels = zip(*[_kitti_like_scan(900 + i, 60_000 + 20_000 * i) for i in range(4)])
+    scans = [s * k for s, k in zip(scans, (1.0, 0.9, 0.75, 1.0))]       # different extents: different grids
+    vs = (0.9, 0.9, 0.9)
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    model.fused_forward = False          # the 16-kernel style contraction (here 4 kernels): K3'
+    batch = sna.PointBatch.from_tiles(scans, labels, device=hip_device)
+    pipe = sna.ScenePipeline(model, (128, 128, 128), keep_labels=[80.0], voxel_dims=vs, per_point=True)
+    with torch.no_grad():
+        out, grids, per_point = pipe(batch, want_gt=True)
+        model.fused_forward = True       # and through linearity (K3L): same chain
+        out_l, per_point_l = pipe(batch)
+    assert grids.status.cpu().tolist() == [0] * 4 and grids.counts is None      # the LDS-bitmap kernels served it
+    assert per_point.shape == (1, batch.total_points)
+    off = batch.offsets.cpu().numpy()
+    seen = set()
+    for b in range(4):
+        counts, towers, gv = vo.voxel_counts(scans[b], None, vs, labels[b], [80.0])
+        nx, ny, nz = (int(v) for v in gv["x_y_z"])
+        seen.add((nx, ny, nz))
+        assert grids.dims[b].cpu().tolist() == [nx, ny, nz] and max(nx, ny, nz) <= 128
+        occ = vo.to_full_dense(vo.normalize_xyz(counts.astype(np.float64)))
+        assert np.array_equal(grids.occ[b, 0].cpu().numpy()[:nz, :nx, :ny], occ > 0)
+        assert np.array_equal(grids.gt_occ[b, 0].cpu().numpy()[:nz, :nx, :ny], towers > 0)
+        ref, _ = _oracle_forward(model, torch.from_numpy(occ)[None, None])       # on the scan's own grid
+        ref = ref[0, 0].numpy()
+        got = out[b, 0].double().cpu().numpy()
+        assert np.abs(got[:nz, :nx, :ny] - ref).max() < TOL
+        assert np.abs(out_l[b, 0].double().cpu().numpy()[:nz, :nx, :ny] - ref).max() < TOL
+        # per point: the prediction of the voxel the oracle bins the point into
+        vx, vy, vz = gv["voxel_x"], gv["voxel_y"], gv["voxel_z"]
+        want = ref[vz, vx, vy]
+        pp = per_point[0, off[b]:off[b + 1]].double().cpu().numpy()
+        assert np.abs(pp - want).max() < TOL
+        assert np.array_equal(pp, got[vz, vx, vy])                               # exactly the voxel's value: same binning
+        assert np.abs(per_point_l[0, off[b]:off[b + 1]].double().cpu().numpy() - want).max() < TOL
+    assert len(seen) > 1
+    # thresholded per-point labels (prob_to_label, voxelization.py:304-323)
+    pipe_tau = sna.ScenePipeline(model, (128, 128, 128), voxel_dims=vs, per_point=True, tau=0.5)
+    with torch.no_grad():
+        _, lab = pipe_tau(batch)
+    assert torch.equal(lab, (per_point_l >= 0.5).to(lab.dtype))
+
+
+def test_single_tile_size_mode_without_a_host_round_trip_in_the_middle(hip_device, golden_dir):
+    """hist_on_voxel / reg_on_voxel(voxel_dims=...): the whole chain on the device with `voxelgrid_dims` as capacity, the
+    tile's own dims read back with the grid; a capacity that is too small falls back to the host-sized route.  Same
+    arrays either way (and as the oracle)."""
+    a = np.load(os.path.join(golden_dir, "ts40k_sample575_subset.npy"))
+    xyz, labels = a[:, :3], a[:, 3]
+    vs = (1.0, 1.0, 1.0)
+    ref = vo.hist_on_voxel(xyz, voxel_dims=vs)
+    big = sna.hist_on_voxel(xyz, (128, 128, 128), voxel_dims=vs)          # fits: cut from the padded grid
+    small = sna.hist_on_voxel(xyz, (8, 8, 8), voxel_dims=vs)              # does not fit: host-sized route
+    assert big.shape == ref.shape == small.shape
+    assert np.array_equal(big, ref) and np.array_equal(small, ref)
+    assert np.array_equal(sna.reg_on_voxel(xyz, labels, [15], (128, 128, 128), voxel_dims=vs),
+                          vo.reg_on_voxel(xyz, labels, [15], voxel_dims=vs))

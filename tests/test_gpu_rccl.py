@@ -1,0 +1,75 @@
+"""Multi-GPU tests that run themselves wherever there are >= 2 HIP devices (the driver's 8-GPU lease), and skip on the
+one-GPU pool: two ranks started by scene-net_amd/launch.py, init_process_group("nccl", device_id=...) = RCCL, one rank per
+device.  The reference's counterpart is pl.Trainer(gpus=-1) (scripts/main.py:228).
+
+What they pin down: (a) allreduce_flat_grads == the single-process mean over the shards; (b) CapturedTrainingStep under
+the live group (two hipGraphs around one all-reduce) leaves bit-identical replicas; (c) `bench.py --gpus 2` forms an RCCL
+group of two and reports it.  On a one-GPU box the same worker is REHEARSED over gloo with both ranks on cuda:0 (the code
+path, not RCCL) -- until a >= 2-GPU run of this file is on record, the RCCL legs are rehearsed only."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "rccl_worker.py")
+
+
+def _launcher():
+    spec = importlib.util.spec_from_file_location("_sn_launch", os.path.join(ROOT, "scene-net_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _run_worker(tmp_path, backend, extra):
+    rc = _launcher().launch_ranks(2, WORKER, [str(tmp_path), backend, *extra], timeout_s=600)
+    assert rc == 0, f"a rank failed (exit {rc})"
+    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+
+
+def _check(res, backend):
+    r0, r1 = res
+    assert r0["world"] == r1["world"] == 2 and r0["backend"] == r1["backend"] == backend
+    assert r0["flat_floats"] == len(r0["flat_grads"]) >= 9
+    for n, v in r0["flat_grads"].items():
+        assert v == r1["flat_grads"][n], n                                   # all-reduced: the same on both ranks
+        ref = r0["ref_grads"][n]
+        assert abs(v - ref) <= 1e-6 + 1e-4 * abs(ref), (n, v, ref)           # == the single-process mean of the shards
+    assert r0["captured_world"] == 2 and r0["two_graphs"] and r1["two_graphs"]
+    assert r0["replicas_bit_identical"] and r1["replicas_bit_identical"]
+    assert r0["params"] == r1["params"]
+    assert all(abs(x) < 1e30 for x in r0["losses"] + r1["losses"])
+
+
+needs_two = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 HIP devices (RCCL, one rank per GPU)")
+
+
+@needs_two
+def test_rccl_flat_gradient_exchange_and_captured_step(tmp_path):
+    res = _run_worker(tmp_path, "nccl", [])
+    assert {r["device"] for r in res} == {0, 1}            # one rank per device
+    _check(res, "nccl")
+
+
+@needs_two
+def test_bench_forms_an_rccl_group_of_two(tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras", "--batch", "4", "--points", "20000", "--sustain-ms", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["per_rank_tiles_per_s"]) == 2
+    assert line["scaling"] == "weak" and line["value"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() != 1, reason="rehearsal for one-GPU boxes (>= 2 devices run the RCCL tests)")
+def test_worker_rehearsed_over_gloo_on_one_gpu(tmp_path):
+    """the same worker, both ranks on cuda:0, process group over gloo: everything but RCCL itself"""
+    res = _run_worker(tmp_path, "gloo", ["--one-gpu"])
+    _check(res, "gloo")

@@ -343,3 +343,77 @@ def test_size_mode_128_cubed_velodyne_scans_full_size(hip_device):
         want = pred[b, 0].cpu().numpy()[gv["voxel_z"], gv["voxel_x"], gv["voxel_y"]]
         assert np.array_equal(got[o:o + len(want)], want)
         o += len(want)
+
+
+def test_size_mode_on_the_lds_bitmap_kernels(hip_device):
+    """voxelize_batch(voxel_dims=...) with only the binary grids wanted (C4's mode) runs sn_voxel_occupancy_sized: the
+    LDS-bitmap kernels on the padded per-tile tables.  Bit-identical to the counting kernels' size mode and to the oracle,
+    occupancy and tower plane, incl. four 120 k-point Velodyne-shaped scans at the 128^3 capacity."""
+    tiles, labels = zip(*[_velodyne_scan(50 + i, 30_000 + 7_000 * i) for i in range(3)])
+    tiles = [t * s for t, s in zip(tiles, (1.0, 0.55, 0.8))]
+    vox = (1.7, 1.9, 1.6)
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    slow = sna.voxelize_batch(batch, (64, 64, 64), [80.0], want_occ=True, want_gt_occ=True, want_counts=True,
+                              voxel_dims=vox, occ_dtype=torch.bool)
+    fast = sna.voxelize_batch(batch, (64, 64, 64), [80.0], want_occ=True, want_gt_occ=True, voxel_dims=vox,
+                              occ_dtype=torch.bool)
+    assert slow.counts is not None and fast.counts is None          # the two paths
+    assert torch.equal(fast.occ, slow.occ) and torch.equal(fast.gt_occ, slow.gt_occ)
+    assert torch.equal(fast.dims, slow.dims) and torch.equal(fast.desc, slow.desc)
+    assert fast.status.cpu().tolist() == [0, 0, 0] and fast.dropped.cpu().tolist() == [0, 0, 0]
+    assert int(fast.flags.sum().item()) == 0                        # every tile has an empty row inside its OWN part
+    for b in range(3):
+        counts, towers, gv = vo.voxel_counts(tiles[b], None, vox, labels[b], [80.0])
+        nx, ny, nz = (int(v) for v in gv["x_y_z"])
+        occ = fast.occ[b, 0].cpu().numpy()
+        assert np.array_equal(occ[:nz, :nx, :ny], vo.to_full_dense(vo.normalize_xyz(counts.astype(np.float64))) > 0)
+        assert occ.sum() == occ[:nz, :nx, :ny].sum()               # nothing outside the tile's own part
+        assert np.array_equal(fast.gt_occ[b, 0].cpu().numpy()[:nz, :nx, :ny], towers > 0)
+    # without the tower plane, f32 output
+    f32 = sna.voxelize_batch(batch, (64, 64, 64), voxel_dims=vox)
+    assert f32.occ.dtype == torch.float32 and torch.equal(f32.occ.bool(), fast.occ)
+    # C4-sized: 4 scans x 120 k points, 128^3 capacity (4 z-slabs; 8 with the tower plane)
+    scans, slab = zip(*[_velodyne_scan(300 + i) for i in range(4)])
+    big = sna.PointBatch.from_tiles(scans, slab, device=hip_device)
+    vs = (0.8, 0.8, 0.8)
+    g = sna.voxelize_batch(big, (128, 128, 128), [80.0], want_occ=True, want_gt_occ=True, voxel_dims=vs,
+                           occ_dtype=torch.bool)
+    assert g.counts is None and g.status.cpu().tolist() == [0] * 4
+    for b in range(4):
+        counts, towers, gv = vo.voxel_counts(scans[b], None, vs, slab[b], [80.0])
+        nx, ny, nz = (int(v) for v in gv["x_y_z"])
+        assert g.dims[b].cpu().tolist() == [nx, ny, nz]
+        assert np.array_equal(g.occ[b, 0].cpu().numpy()[:nz, :nx, :ny], counts > 0)
+        assert np.array_equal(g.gt_occ[b, 0].cpu().numpy()[:nz, :nx, :ny], towers > 0)
+
+
+def test_size_mode_full_column_takes_the_exact_fallback(hip_device):
+    """a tile whose OWN part has no empty (z, x) row -- here: a y column occupied in every row -- must not be served by
+    `count > 0`: the padding rows are empty but are not part of the reference's grid.  The flag goes up, the gated counting
+    kernel redoes the tile with the column minima of its own part, and the result equals the counting kernels' size mode."""
+    rng = np.random.default_rng(9)
+    vs = (1.0, 1.0, 1.0)
+    base = np.concatenate([rng.uniform(0.2, 5.8, (400, 3)), np.array([[0.0, 0.0, 0.0], [6.0, 6.0, 6.0]])])
+    gv = vo.voxelgrid_compute(base, sizes=vs)                      # the grid the size mode gives this box
+    ex, ey, ez = gv["segments"]
+    cx, cy, cz = [(e[:-1] + e[1:]) / 2 for e in (ex, ey, ez)]
+    j0 = 2                                                         # one point at the centre of every (z, x) row's cell y = j0
+    col = np.stack(np.meshgrid(cx, [cy[j0]], cz, indexing="ij"), -1).reshape(-1, 3)
+    col = col[(col >= 0.0).all(1) & (col <= 6.0).all(1)]           # (inside the box: it, hence the grid, is unchanged)
+    edge_rows = len(cx) * len(cz) - len(col)
+    pts = np.concatenate([base, col])
+    g2 = vo.voxelgrid_compute(pts, sizes=vs)
+    assert np.array_equal(g2["xyzmin"], gv["xyzmin"]) and np.array_equal(g2["x_y_z"], gv["x_y_z"])
+    batch = sna.PointBatch.from_tiles([pts], device=hip_device)
+    slow = sna.voxelize_batch(batch, (32, 32, 32), want_occ=True, want_counts=True, voxel_dims=vs, occ_dtype=torch.bool)
+    fast = sna.voxelize_batch(batch, (32, 32, 32), want_occ=True, voxel_dims=vs, occ_dtype=torch.bool)
+    counts, _, gv = vo.voxel_counts(pts, None, vs)
+    rows_empty = int((counts.sum(axis=2) == 0).sum())              # (z, x) rows of the tile's OWN grid without a point
+    if edge_rows == 0:
+        assert rows_empty == 0
+    assert int(fast.flags[0].item()) == (1 if rows_empty == 0 else 0)
+    assert torch.equal(fast.occ, slow.occ) and torch.equal(fast.dims, slow.dims)
+    nx, ny, nz = (int(v) for v in gv["x_y_z"])
+    want = vo.to_full_dense(vo.normalize_xyz(counts.astype(np.float64))) > 0
+    assert np.array_equal(fast.occ[0, 0].cpu().numpy()[:nz, :nx, :ny], want)
+    assert rows_empty == 0 and not np.array_equal(want, counts > 0)   # the case really differs from `count > 0`

@@ -53,17 +53,14 @@ def main():
     model = model.to(dev)
     scans, labels = zip(*[kitti_like_scan(s) for s in range(args.batch)])
     batch = sna.PointBatch.from_tiles(scans, labels, device=dev)
-    pipe = sna.ScenePipeline(model, (args.grid,) * 3, keep_labels=[80.0])
+    # C4 as ONE call: (size-mode | n-mode) grids -> bank conv + head -> per-point read-back (scene-net_amd/pipeline.py)
+    pipe = sna.ScenePipeline(model, (args.grid,) * 3, keep_labels=[80.0], voxel_dims=args.voxel_size, per_point=True,
+                             tau=0.5)
 
     def step():
         with torch.no_grad():
-            if args.voxel_size is None:
-                pred, grids = pipe(batch, want_gt=True)
-            else:   # size mode: bbox -> per-scan descriptor on the device -> counting scatter -> padded binary grids
-                grids = sna.voxelize_batch(batch, (args.grid,) * 3, [80.0], want_occ=True, want_gt_occ=True,
-                                           voxel_dims=args.voxel_size, occ_dtype=torch.bool)
-                pred = model(grids.occ)
-            return sna.point_predictions(pred, batch, grids, tau=0.5), grids
+            pred, grids, per_point = pipe(batch, want_gt=True)
+            return per_point, grids
 
     import gc
     gc.collect()
@@ -85,6 +82,9 @@ def main():
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / args.iters
     npts = batch.total_points
+    if grids.status is not None:   # (a size / capacity pair that overflows measures clipped tiles)
+        assert int(grids.status.sum()) == 0, f"voxel size {args.voxel_size} needs more than {args.grid}^3: {grids.dims.tolist()}"
+    print("points dropped by the binning:", int(grids.dropped.sum()))
     mode = "n-mode grid" if args.voxel_size is None else f"voxel size {tuple(args.voxel_size)}, dims {grids.dims[0].tolist()}.."
     print(f"C4-like ({mode}): {args.batch} scans x {npts // args.batch} points, {args.grid}^3: {ms:.3f} ms/batch = "
           f"{args.batch / ms * 1e3:.0f} scans/s = {npts / ms * 1e3 / 1e6:.0f} Mpoints/s; occupancy "

@@ -19,7 +19,7 @@ python bench.py --grid 128 --batch 32 --points 120000 --steps 10 --warmup 2 --no
 python3 tools/train_step_bench.py --graph --iters 20 > $O/train_bench.txt 2>&1 || true
 python3 tools/train_step_bench.py --graph --iters 20 --bf16 > $O/train_bench_bf16.txt 2>&1 || true
 python tools/c4_bench.py --batch 32 > $O/c4.txt 2>&1 || true
-python tools/c4_bench.py --batch 32 --voxel-size 0.8 0.8 0.8 >> $O/c4.txt 2>&1 || true
+python tools/c4_bench.py --batch 32 --voxel-size 0.9 0.9 0.9 >> $O/c4.txt 2>&1 || true   # (0.9 m: the ~100 m scans fit 128^3)
 python tools/conv_ab.py --rounds 3 > $O/conv_ab.txt 2>&1 || true
 # PMC passes
 mkdir -p $O/pmc
