@@ -157,7 +157,7 @@ extern "C" int sn_set_option(const char* name, int value) {
         return SN_OK;
     }
     if (strcmp(name, "conv_i8z_variant") == 0) {
-        if (value < 0 || value > 3) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: conv_i8z_variant is 0 .. 3");
+        if (value < 0 || value > 2) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: conv_i8z_variant is 0, 1 or 2");
         sn::g_i8z_variant.store(value, std::memory_order_relaxed);
         return SN_OK;
     }

@@ -40,6 +40,7 @@
 namespace {
 
 #include "conv_prep.h"
+#include "conv_fp32.inc"   // fp32k::conv_bank_body: the fp32 form, for the combined fallback launch (conv_i8_fallback_kernel)
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
@@ -395,6 +396,9 @@ __device__ __forceinline__ void finish_round(const SH& s, const TileCoord& c, in
         // the head's mix: sum_r lam_r (low_r + 65536 hi_r) as two packed FMAs per kernel and PAIR of tiles, straight
         // from the integer accumulators (the same bits with or without `act`) -- 128 VALU per round instead of 164 (a VALU instruction costs the SIMD about
         // 2.5 cycles next to a busy matrix pipe: tools/micro/mfma_valu_mix.hip)
+        // ([measured] round 3: recombining the three digit sums in int32 -- one conversion and one FMA per kernel and voxel,
+        // for banks whose weights cannot sum past int32 -- was built in all four kernels and is not faster: z-walk 108.4 vs
+        // 107.3 us, folded 124.1 vs 121.6, stride-4 199.6 vs 194.8; two dependent shift-adds replace one conversion)
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         const float4 hi4 = *reinterpret_cast<const float4*>(lamhi + 4 * q);
         const float lhi[4] = {hi4.x, hi4.y, hi4.z, hi4.w};
@@ -461,11 +465,12 @@ __device__ unsigned long long g_i8s_w[1024 * 8 * 8];   // [workgroup][wave][phas
 // <10, 6, 1> --, which makes every tail slot's kind and the peeled end of the pair loop static (one code path: with the
 // run-time form hipcc keeps a second copy of the 96 accumulator registers across the join and spills); kNT < 0: taken
 // from the shape.
+// returns true when the quantisation guard sent the launch to the fp32 form (nothing written; *s.route = 1 if s.route)
 template <typename OT, int kNP, int kNT, int kODD>
-__device__ __forceinline__ void conv_occ_i8s_body(const uint8_t* __restrict__ x, const float* __restrict__ bank,
+__device__ __forceinline__ bool conv_occ_i8s_body(const uint8_t* __restrict__ x, const float* __restrict__ bank,
                                                   const float* __restrict__ lambdas, const Shape& s,
                                                   OT* __restrict__ act, OT* __restrict__ out) {
-    if (!s.gate.pass()) return;
+    if (!s.gate.pass()) return false;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: what derives from it (a round's rows,
@@ -519,7 +524,7 @@ __device__ __forceinline__ void conv_occ_i8s_body(const uint8_t* __restrict__ x,
         if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
         if (exceeded) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // do not leave with LDS-DMA in flight
-            return;
+            return true;
         }
     }
     // ---- digit table Wd[st][d][l = (qq, g)]: 4 dwords j, slot (st, qq, j)
@@ -593,7 +598,7 @@ __device__ __forceinline__ void conv_occ_i8s_body(const uint8_t* __restrict__ x,
     }
     if (my_tiles == 0 || (s.dbg & 8)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
+        return false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the first two halos are in
     __syncthreads();                                   // tables complete, every wave's pieces in: no counters needed yet
@@ -904,6 +909,7 @@ __device__ __forceinline__ void conv_occ_i8s_body(const uint8_t* __restrict__ x,
     }
     if (!healthy && lane == 0) atomicAdd(&g_fold_counts[3], 1ull);   // reported: sn_conv_i8_spin_timeouts
     SN_ST(5);
+    return false;
 }
 
 // the stride-4 kernel as a launch of its own (banks the folded kernel is not tried on)
@@ -912,7 +918,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8s_kernel(const uint8_t* _
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ lambdas, Shape s,
                                                                 OT* __restrict__ act, OT* __restrict__ out) {
-    conv_occ_i8s_body<OT, kNP, kNT, kODD>(x, bank, lambdas, s, act, out);
+    (void)conv_occ_i8s_body<OT, kNP, kNT, kODD>(x, bank, lambdas, s, act, out);
 }
 
 // ================================================================================================ folded kernel
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
         if (blockIdx.x == 0 && tid == 0) atomicAdd(&g_fold_counts[1], 1ull);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        conv_occ_i8s_body<OT, 10, 6, 1>(x, bank, lambdas, s, act, out);
+        (void)conv_occ_i8s_body<OT, 10, 6, 1>(x, bank, lambdas, s, act, out);
         return;
     }
     SN_ST(6);   // (symmetry checked)
@@ -1483,6 +1489,7 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
                  int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
                  hipStream_t stream) {
     if (ky != 9 || kz != 9 || kx != 9 || Y % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || G > 16) return 1;
+    if ((long long)Z * X * Y >= (1ll << 31)) return 1;   // offsets inside a tile are 32-bit in the walk
     if (act && (reinterpret_cast<uintptr_t>(act) & 15)) return 1;
     if (out && (reinterpret_cast<uintptr_t>(out) & 15)) return 1;
     if (!prep || (reinterpret_cast<uintptr_t>(prep) & 15)) return 1;
@@ -1498,13 +1505,17 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     s4.dynamic = 1;
     if (!plan_stride4(s4, B, Z, X, Y, kz, kx, cus)) return 1;
     s4.tol = sn::option_conv_i8_tolerance();
-    s4.route = reinterpret_cast<int32_t*>(prep + kPrepRoute);
+    s4.route = nullptr;   // (the fallback launch reads the walk's verdict; the body must not rewrite it under other workgroups)
+    int32_t* const route = reinterpret_cast<int32_t*>(prep + kPrepRoute);
+    fp32k::ConvShape cs;
+    bool dbl = false;
+    if (!fp32k::plan_fp32(cs, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky, cus, false, dbl)) return 1;
     ZShape z;
     memset(&z, 0, sizeof(z));
     z.B = B; z.Z = Z; z.X = X; z.Y = Y; z.G = G; z.Gtot = Gtot; z.g0 = g0; z.head = head;
     z.gate = s4.gate;
     z.tol = s4.tol;
-    z.route = s4.route;
+    z.route = route;
     z.nxt = (X + kZTX - 1) / kZTX;
     z.nyt = (Y + TY - 1) / TY;
     const long long ncol = (long long)B * z.nxt * z.nyt;
@@ -1535,15 +1546,16 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     if (per_wg > kZMaxJobs) return 1;
     if (!division_magic((unsigned)z.PL, (unsigned)(per_wg * z.PL + 64), z.pl_magic)) return 1;
     z.swizzle = (grid % 8 == 0) ? 1 : 0;
-    const size_t lds_z = lds_bytes_zwalk(), lds_4 = lds_bytes(s4);
-    const size_t lds = lds_z > lds_4 ? lds_z : lds_4;
-    if (lds > (size_t)kMaxLds) return 1;
+    const size_t lds = lds_bytes_zwalk();
+    const size_t lds_4 = lds_bytes(s4), lds_f = fp32k::lds_bytes(cs, false);
+    const size_t lds_fb = lds_4 > lds_f ? lds_4 : lds_f;
+    if (lds > (size_t)kMaxLds || lds_fb > (size_t)kMaxLds) return 1;
 #define SN_LAUNCH_I8Z(OT, KH, KR, KW)                                                                            \
     do {                                                                                                         \
         auto kern = conv_occ_i8z_kernel<OT, KH, KR, KW>;                                                         \
         if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
             return check_launch("sn_conv_bank_prepared(i8z: hipFuncSetAttribute)");                              \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, stream, x, bank, lambdas, (const uint8_t*)prep, z, s4, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, stream, x, lambdas, (const uint8_t*)prep, z,       \
                            (OT*)act, (OT*)out);                                                                  \
     } while (0)
 #define SN_LAUNCH_I8Z_V(KH, KR, KW)                                                                              \
@@ -1552,23 +1564,31 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
         else SN_LAUNCH_I8Z(double, KH, KR, KW);                                                                  \
     } while (0)
     // the shape of a ticket: rounds of two x-rows on 8 waves (2 per SIMD, the tile kernels' round), or rounds of one
-    // x-row -- half the accumulator registers -- on 12 waves (3 per SIMD), one, two or four of them per ticket
+    // x-row -- half the accumulator registers -- on 12 waves (3 per SIMD), one or two of them per ticket
     switch (sn::option_conv_i8z_variant()) {
         case 0: SN_LAUNCH_I8Z_V(2, 1, 8); break;
         case 1: SN_LAUNCH_I8Z_V(1, 1, 12); break;
-        case 3: SN_LAUNCH_I8Z_V(1, 4, 12); break;
         default: SN_LAUNCH_I8Z_V(1, 2, 12); break;
     }
 #undef SN_LAUNCH_I8Z_V
 #undef SN_LAUNCH_I8Z
     if (int rc = check_launch("sn_conv_bank_prepared(i8z)")) return rc;
-    if (z.tol > 0.0f) {
-        // the same launch on the fp32 matrix pipe, enqueued behind: runs only if the guard sent it there
-        sn::GateScope guard(z.route, 1);
-        return sn::conv_bank_group(x, SN_U8, bank, lambdas, B, Z, X, Y, G, Gtot, g0, head, kz, kx, ky, act, out,
-                                   out_dtype, reinterpret_cast<sn_stream_t>(stream));
+    // the combined fallback launch: exits at once unless the walk's verdict sent the job on (unfolded int8 body / fp32 form)
+    {
+        const int fgrid = cus;
+#define SN_LAUNCH_FB(OT)                                                                                         \
+    do {                                                                                                         \
+        auto kern = conv_i8_fallback_kernel<OT>;                                                                 \
+        if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
+            return check_launch("sn_conv_bank_prepared(fallback: hipFuncSetAttribute)");                         \
+        hipLaunchKernelGGL(kern, dim3(fgrid), dim3(kThreads), lds_fb, stream, x, bank, lambdas, (const int32_t*)route, s4, \
+                           cs, (OT*)act, (OT*)out);                                                              \
+    } while (0)
+        if (out_dtype == SN_F32) SN_LAUNCH_FB(float);
+        else SN_LAUNCH_FB(double);
+#undef SN_LAUNCH_FB
     }
-    return SN_OK;
+    return check_launch("sn_conv_bank_prepared(fallback)");
 }
 
 }  // namespace sn

@@ -28,8 +28,9 @@ constexpr int kPrepBnd = 12352;                // double [16]        worst-case 
 constexpr int kPrepSym = 12480;                // int [16]           1: kernel g is bit-for-bit symmetric in x and y
 constexpr int kPrepFit = 12544;                // int [16]           1: every partial digit recombination fits int32
 constexpr int kPrepMagic = 12608;              // int                0x5a57414c once written
+constexpr int kPrepZero = 12800;               // 16 zero bytes (the z-walk's LDS-DMA source for pieces outside the grid)
 constexpr int kPrepRoute = 12672;              // int                the caller-owned route flag of the launches using this blob
-static_assert(kPrepRoute + 4 <= SN_CONV_PREP_BYTES, "blob layout");
+static_assert(kPrepRoute + 4 <= kPrepZero && kPrepZero + 16 <= SN_CONV_PREP_BYTES && kPrepZero % 16 == 0, "blob layout");
 
 // slot -> folded kernel row of lane group qq (the z-walk plan; regular slots as FoldPlan: planes dz = 2 qq + a)
 __host__ __device__ constexpr int zplan_krow(int qq, int slot) {
@@ -156,6 +157,9 @@ __device__ __forceinline__ void prep_one_kernel(float* w, int* asym_s, bool vali
         reinterpret_cast<int*>(prep + kPrepSym)[g] = *asym_s ? 0 : 1;
         // |sum of any subset of the 729 signed weights x {0,1}| stays below 2^31: the digit sums may be recombined in int32
         reinterpret_cast<int*>(prep + kPrepFit)[g] = (qp < 2147483000.0 && qn < 2147483000.0) ? 1 : 0;
-        if (g == 0) *reinterpret_cast<int*>(prep + kPrepMagic) = 0x5a57414c;
+        if (g == 0) {
+            *reinterpret_cast<int*>(prep + kPrepMagic) = 0x5a57414c;
+            *reinterpret_cast<uint4*>(prep + kPrepZero) = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 }

@@ -31,8 +31,13 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxKeep = 16;
-constexpr int kOccThreads = 512;
-constexpr int kOccParts = SN_OCC_PARTS;
+#ifndef SN_OCC_THREADS
+#define SN_OCC_THREADS 512
+#endif
+constexpr int kOccThreads = SN_OCC_THREADS;
+// partial bitmaps per tile: SN_OCC_PARTS sizes the workspace; fewer, larger workgroups write (and the finalize kernel
+// ORs) fewer of them
+constexpr int kOccParts = SN_OCC_PARTS * 512 / SN_OCC_THREADS;
 constexpr int kMaxOccWords = 16 * 1024;  // 64 KiB of LDS bitmap per workgroup (occ + tower share it)
 
 struct KeepLabels {

@@ -28,9 +28,9 @@ def _symmetric_bank(G, seed, scale=None):
     return (w * scale.view(G, 1, 1, 1)).float().contiguous()
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["2rows_8waves", "1row_12waves", "1rowx2_12waves", "1rowx4_12waves"], autouse=True)
+@pytest.fixture(params=[0, 1, 2], ids=["2rows_8waves", "1row_12waves", "1rowx2_12waves"], autouse=True)
 def zwalk_variant(request):
-    """every test runs on the four shapes of the walk's rounds (sn_set_option "conv_i8z_variant")"""
+    """every test runs on the three shapes of the walk's rounds (sn_set_option "conv_i8z_variant")"""
     default = _hip.get_option("conv_i8z_variant")
     _hip.set_option("conv_i8z_variant", request.param)
     yield request.param
@@ -205,3 +205,44 @@ def test_pipeline_with_the_bank_forked_beside_the_voxelisation(hip_device):
         assert torch.equal(serial, replayed)
     model.fused_forward = True
     assert _hip.conv_i8_spin_timeouts() == 0
+
+
+def test_all_positive_and_zero_mean_banks_agree_in_every_int8_kernel(hip_device):
+    """z-walk == folded == stride-4 == four-copy bit for bit, and within 1e-4 of the fp64 oracle, on a zero-mean bank (what
+    GENEO banks look like) and on an all-positive one, whose digit sums run into the tens of bits -- the case where an int32
+    recombination of the three digit sums would overflow (the blob's `fit` field says so; round 3 built that one-conversion
+    head in all four kernels, measured no gain and took it out again: DESIGN section 9)."""
+    torch.manual_seed(21)
+    occ = torch.rand((2, 1, 24, 16, 64)) < 0.35
+    g = torch.Generator().manual_seed(5)
+    w = torch.rand((16, 9, 9, 9), generator=g)
+    w = w + w.flip(2)
+    w = w + w.flip(3)
+    banks = {"no fit (all weights positive: sum of Q ~ 729 x 4e6 > 2^31)": (0.004 * (w + 1.0)).float().contiguous(),
+             "fit (zero-mean)": (0.01 * (w - w.mean())).float().contiguous()}
+    lam = (torch.rand(16) - 0.3) / 16
+    x, l = occ.to(hip_device), lam.to(hip_device)
+    for name, bank in banks.items():
+        b = bank.to(hip_device)
+        prep = _hip.conv_bank_prep(b)
+        fit = prep[12544:12544 + 64].cpu().numpy().view(np.int32)
+        assert bool(fit.all()) == name.startswith("fit"), (name, fit.tolist())
+        ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+        ref_out = torch.relu(torch.tanh((lam.double().view(1, 16, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
+        outs = {"zwalk": _hip.conv_bank(x, b, l, want_act=True, want_out=True, prep=prep)}
+        outs["folded"] = _hip.conv_bank(x, b, l, want_act=True, want_out=True)
+        _hip.set_option("conv_i8_fold", 0)
+        try:
+            outs["stride-4"] = _hip.conv_bank(x, b, l, want_act=True, want_out=True)
+        finally:
+            _hip.set_option("conv_i8_fold", 1)
+        _hip.set_option("conv_i8_legacy", 1)
+        try:
+            outs["four-copy"] = _hip.conv_bank(x, b, l, want_act=True, want_out=True)
+        finally:
+            _hip.set_option("conv_i8_legacy", 0)
+        a0, o0 = outs["zwalk"]
+        for k, (a, o) in outs.items():
+            assert torch.equal(a, a0) and torch.equal(o, o0), (name, k)
+        assert (o0.cpu().double() - ref_out).abs().max().item() < TOL, name
+        assert (a0.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item()), name

@@ -50,7 +50,6 @@ def main():
         "zwalk 2x1x8+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=0),
         "zwalk 1x1x12+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=1),
         "zwalk 1x2x12+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=2),
-        "zwalk 1x4x12+guard": dict(legacy=0, tol=90000, fold=1, prep=True, zv=3),
         "zwalk 1x2x12 noguard": dict(legacy=0, tol=0, fold=1, prep=True, zv=2),
         "folded+guard": dict(legacy=0, tol=90000, fold=1),
         "folded noguard": dict(legacy=0, tol=0, fold=1),
