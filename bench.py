@@ -58,8 +58,10 @@ def parse():
                     help="untimed spin-up of the same step before the warm-up steps (device clocks settle)")
     ap.add_argument("--event-every", type=int, default=0,
                     help="record the HIP events that time the stages on every N-th timed step; 0 (default) = "
-                         "4 (1 below 8 steps).  [measured] a record costs ~2.5 us of GPU time: 0.2547 / "
-                         "0.2446 / 0.2417 ms per step with the four records on every / every 4th / one timed step")
+                         "max(5, steps / 8) (1 below 8 steps): at least four timed launches at the default 20 steps, "
+                         "eight at 64 and more.  [measured] a record costs ~2.5 us of GPU time plus host work next to "
+                         "a queue that is barely ahead: 187.3 / 159.1 us per step with the records on every 4th / "
+                         "every 50th of 200 steps")
     ap.add_argument("--sustain-ms", type=float, default=400.0,
                     help="also time the same eager step back to back over at least this much wall time "
                          "(`value_sustained`; 0 = skip)")
@@ -190,7 +192,12 @@ def main():
     pipe = sna.ScenePipeline(model, dims)
     del tiles, labels
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (recorded on the launch stream)
+    # HIP events that time the stages live, inside the timed loop, on the launch stream.  They are created BEFORE the loop
+    # (building one costs the host ~5-10 us, and the eager step is within 10 % of being host bound) and recorded on every
+    # --event-every'th step only: [measured] round 3, 200 steps: 187.3 us/step with the records on every 4th step, 159.1 on
+    # every 50th -- a record is ~2.5 us of GPU time and the host work around it starves the queue.
+    _pool = [torch.cuda.Event(enable_timing=True) for _ in range(4 * (args.steps + 8))]
+    ev = lambda: _pool.pop() if _pool else torch.cuda.Event(enable_timing=True)  # noqa: E731
     conv_ev, vox_ev = [], []
 
     def step(timed):
@@ -207,7 +214,9 @@ def main():
         if timed:
             c0 = ev()
             c0.record()
-        _, out = sna._hip.conv_bank(grids.occ, bank, lam, want_act=False, want_out=True, prep=prep)
+        # (the walk's verdict for these parameters is learnt asynchronously during the warm-up; from then on the empty
+        # fallback launch behind the walk is left out: scene_net.py, contract_prepared)
+        _, out = model.contract_prepared(grids.occ, bank, lam, prep)
         if timed:
             c.record()
             vox_ev.append((a, b))
@@ -264,7 +273,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     served_before = sna._hip.conv_i8_path_counts()[0]   # launches the folded int8 kernel has served so far
-    event_every = args.event_every if args.event_every > 0 else (4 if args.steps >= 8 else 1)
+    event_every = args.event_every if args.event_every > 0 else (max(5, args.steps // 8) if args.steps >= 8 else 1)
     fence()
     t0 = time.perf_counter()
     for i_ in range(args.steps):

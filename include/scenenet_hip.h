@@ -165,6 +165,17 @@ int sn_conv_bank_prep(const float* bank, int G, int kz, int kx, int ky, void* pr
 int sn_conv_bank_prepared(const void* x, int x_dtype, const float* bank, const float* lambdas, void* prep,
                           int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
                           void* act, void* out, int out_dtype, sn_stream_t stream);
+/* sn_conv_bank_prepared without the fallback launch behind the walk.  The walk's verdict -- 0 served, 1 quantisation bound
+ * over the tolerance (fp32 form), 2 bank not symmetric (unfolded body) -- is an int32 at byte offset
+ * sn_conv_prep_verdict_offset() of each group's blob, written by every walk launch; it depends on the weights, the
+ * coefficients, the tolerance and on which outputs are asked for, on nothing else.  A caller that has READ it as 0 for
+ * exactly these (e.g. a serving loop whose parameters do not change: read it back once, asynchronously) may use this entry:
+ * the ~3 us empty dispatch of the fallback launch disappears.  If the verdict is not 0 the outputs are NOT written (the
+ * verdict still is): only for callers that checked. */
+int sn_conv_bank_prepared_served(const void* x, int x_dtype, const float* bank, const float* lambdas, void* prep,
+                                 int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
+                                 void* act, void* out, int out_dtype, sn_stream_t stream);
+int sn_conv_prep_verdict_offset(void);
 /* Diagnostics: how many waves of the int8 kernels ever gave up a bounded LDS hand-over spin (must stay 0: a non-zero
  * count means a launch may have read a ring slot that had not landed).  Synchronises the device. */
 int sn_conv_i8_spin_timeouts(unsigned long long* count);

@@ -39,6 +39,8 @@ SYMBOLS = {
     "sn_geneo_bank_prep": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "sn_conv_bank_prep": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "sn_conv_bank_prepared": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_conv_bank_prepared_served": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "sn_conv_prep_verdict_offset": (c_int, []),
     "sn_conv_i8_spin_timeouts": (c_int, [_P]),
     "sn_conv_fused": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sn_conv_fused_supported": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
@@ -270,6 +272,45 @@ def geneo_bank_prep(params: torch.Tensor, kinds: torch.Tensor, lambdas: Optional
     return bank, (lam_out if lambdas is not None else None), prep
 
 
+def prep_verdicts(prep: torch.Tensor) -> torch.Tensor:
+    """view of the walk's verdict words (int32, one per group of 16 kernels) inside a preparation blob"""
+    off = int(load().sn_conv_prep_verdict_offset())
+    return prep.view(-1, SN_CONV_PREP_BYTES)[:, off:off + 4].view(torch.int32).reshape(-1)
+
+
+class PreparedVerdict:
+    """Learns, WITHOUT synchronising, whether the launches of one (weights, coefficients, tolerance, outputs) combination
+    are served by the z-walk, so that later launches of the same combination can leave the fallback launch out
+    (sn_conv_bank_prepared_served).  After a launch made with the fallback in place, `note(prep, key)` enqueues a 4-byte
+    copy of the verdict words into pinned host memory and records an event; `served(key)` is True once that copy has
+    completed and read 0 -- until then (and for every new key: an optimiser step changes it) the caller keeps the fallback."""
+
+    def __init__(self):
+        self._key = None
+        self._state = 0          # 0 nothing known, 1 read-back in flight, 2 served, 3 not served
+        self._host = None
+        self._event = None
+
+    def served(self, key) -> bool:
+        if key != self._key:
+            self._key, self._state = key, 0
+            return False
+        if self._state == 1 and self._event.query():
+            self._state = 2 if int(self._host.abs().max()) == 0 else 3
+        return self._state == 2
+
+    def note(self, prep: torch.Tensor, key) -> None:
+        if key != self._key or self._state != 0 or torch.cuda.is_current_stream_capturing():
+            return
+        words = prep_verdicts(prep)
+        if self._host is None or self._host.numel() != words.numel():
+            self._host = torch.empty(words.numel(), dtype=torch.int32, pin_memory=True)
+        self._host.copy_(words, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._state = 1
+
+
 @_on_tensor_device
 def conv_bank_prep(bank: torch.Tensor, prep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The per-bank work of the int8 contraction, once (sn_conv_bank_prep): symmetry verdict, 24-bit fixed-point weights,
@@ -289,10 +330,13 @@ def conv_bank_prep(bank: torch.Tensor, prep: Optional[torch.Tensor] = None) -> t
 
 @_on_tensor_device
 def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tensor], want_act: bool = False,
-              want_out: bool = True, out_dtype: Optional[torch.dtype] = None, prep: Optional[torch.Tensor] = None):
+              want_out: bool = True, out_dtype: Optional[torch.dtype] = None, prep: Optional[torch.Tensor] = None,
+              assume_served: bool = False):
     """x [B,1,Z,X,Y] (f32|f64|u8|bool), bank [G,kz,kx,ky] f32, lambdas [G] f32 (effective) ->
     (act [B,G,Z,X,Y] | None, out [B,1,Z,X,Y] | None) of out_dtype (sn_conv_bank; with `prep` = conv_bank_prep(bank):
-    sn_conv_bank_prepared -- same results bit for bit, the per-bank work not repeated)."""
+    sn_conv_bank_prepared -- same results bit for bit, the per-bank work not repeated; `assume_served`: the caller has
+    read the blob's verdict as 0 for these weights / coefficients / tolerance / outputs: sn_conv_bank_prepared_served, no
+    fallback launch -- see PreparedVerdict)."""
     if x.dim() != 5 or x.shape[1] != 1:
         raise HipLibraryError(f"x must be [B,1,Z,X,Y] (got {tuple(x.shape)})")
     if x.dtype not in _DT or x.dtype == torch.bfloat16:
@@ -306,10 +350,11 @@ def conv_bank(x: torch.Tensor, bank: torch.Tensor, lambdas: Optional[torch.Tenso
     if prep is not None:
         if prep.dtype != torch.uint8 or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
             raise HipLibraryError("prep: not a blob of conv_bank_prep for this bank")
-        rc = load().sn_conv_bank_prepared(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
-                                          _ptr(lambdas, torch.float32, "lambdas"), _ptr(prep, torch.uint8, "prep"),
-                                          B, Z, X, Y, G, kz, kx, ky, _ptr(act, None, "act"), _ptr(out, None, "out"),
-                                          _DT_OUT[out_dtype], _stream())
+        fn = load().sn_conv_bank_prepared_served if assume_served else load().sn_conv_bank_prepared
+        rc = fn(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                _ptr(lambdas, torch.float32, "lambdas"), _ptr(prep, torch.uint8, "prep"),
+                B, Z, X, Y, G, kz, kx, ky, _ptr(act, None, "act"), _ptr(out, None, "out"),
+                _DT_OUT[out_dtype], _stream())
         _check(rc, "sn_conv_bank_prepared")
         return act, out
     rc = load().sn_conv_bank(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),

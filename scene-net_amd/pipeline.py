@@ -119,7 +119,8 @@ class ScenePipeline:
             if model.fused_forward and _hip.conv_fused_supported(x, model.kernel_size_of_bank()):
                 out = _hip.conv_fused(x, bank, lam, out_dtype=model.activation_dtype or torch.float32)
             else:
-                out = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True, prep=prep)[1]
+                out = (model.contract_prepared(x, bank, lam, prep)[1] if prep is not None and x.dtype == torch.bool
+                       else _hip.conv_bank(x, bank, lam, want_act=False, want_out=True)[1])
             return self._finish(out, grids, batch, want_gt)
 
     def capture(self, batch: PointBatch, want_gt: bool = False) -> "CapturedPipeline":

@@ -192,14 +192,23 @@ class SceneNet(nn.Module):
 
     # ------------------------------------------------------------------ host logic
     def kernel_size_of_bank(self) -> Tuple[int, int, int]:
-        sizes = {tuple(int(k) for k in layer.kernel_size) for layer in self.geneos.values()}
+        layers = tuple(self.geneos._modules.values())
+        cached = self.__dict__.get("_ks_cache")
+        if cached is not None and len(cached[0]) == len(layers) and all(a is b for a, b in zip(cached[0], layers)) \
+                and all(l.kernel_size is k for l, k in zip(layers, cached[1])):
+            return cached[2]
+        sizes = {tuple(int(k) for k in layer.kernel_size) for layer in layers}
         if len(sizes) != 1:
             raise RuntimeError(f"GENEO kernels of different sizes cannot be stacked: {sizes}")  # torch.stack fails
-        return next(iter(sizes))
+        ks = next(iter(sizes))
+        self.__dict__["_ks_cache"] = (layers, tuple(l.kernel_size for l in layers), ks)
+        return ks
 
     def packed_params(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
         """([G, SN_NPARAM] f32, [G] i32) on `device`; re-packed only when a parameter changed."""
-        key = (str(device),) + tuple((id(p), p._version) for l in self.geneos.values() for p in l.geneo_params.values())
+        # (the key walks the plain dicts behind ModuleDict / ParameterDict: through their public iterators this one line
+        # cost ~30 us of the eager step's ~150 us of host time)
+        key = (device,) + tuple((id(p), p._version) for p in self._geneo_leaves())
         if self._pack_cache is not None and self._pack_cache[0] == key:
             return self._pack_cache[1], self._pack_cache[2]
         rows, kinds = [], []
@@ -225,14 +234,14 @@ class SceneNet(nn.Module):
         reference's side effect of re-creating lambdas_dict[last_lambda] (SCENE_Net.py:333)."""
         # ~17 tiny dependent device ops: redone only when a coefficient (or last_lambda) changed since the last
         # call -- 1 - sum(others) is then already what lambdas_dict[last_lambda] holds.
-        key = (str(device), self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict.values())
+        key = (device, self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict._parameters.values())
         if self._lambda_cache is not None and self._lambda_cache[0] == key:
             return self._lambda_cache[1]
         last = 1 - sum(self.lambdas_dict.values()) + self.lambdas_dict[self.last_lambda]
         self.lambdas_dict[self.last_lambda] = nn.Parameter(last.detach(), requires_grad=False)
         vals = [self.lambdas_dict[f"lambda_{g}"].detach() for g in self.geneos]
         lam = torch.stack(vals).to(device=device, dtype=torch.float32).contiguous()
-        key = (str(device), self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict.values())
+        key = (device, self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict._parameters.values())
         self._lambda_cache = (key, lam)
         return lam
 
@@ -259,6 +268,24 @@ class SceneNet(nn.Module):
             self.__dict__["_prepared_bufs"] = bufs
         bank, _, prep = _hip.geneo_bank_prep(params, kinds, bank=bufs[0], prep=bufs[1])
         return bank, prep
+
+    def contract_prepared(self, x: torch.Tensor, bank: torch.Tensor, lam: torch.Tensor, prep: torch.Tensor,
+                          want_act: bool = False, out_dtype: Optional[torch.dtype] = None):
+        """sn_conv_bank_prepared on (bank, lam, prep) of THIS model's current parameters -> (act | None, out).  The walk's
+        verdict (served / fp32 form / unfolded body) depends on the weights, the coefficients, the tolerance and the
+        outputs asked for: once it has been read back as "served" for the current parameter versions -- asynchronously,
+        no synchronisation (_hip.PreparedVerdict) -- the empty fallback launch behind the walk is left out, until a
+        parameter changes."""
+        key = (x.device, bool(want_act), _hip.get_option("conv_i8_tolerance_ppb"),
+               self._pack_cache[0] if self._pack_cache is not None else None,
+               self._lambda_cache[0] if self._lambda_cache is not None else None, prep.data_ptr())
+        verdict = self.__dict__.setdefault("_prepared_verdict", _hip.PreparedVerdict())
+        served = verdict.served(key)
+        res = _hip.conv_bank(x, bank, lam, want_act=want_act, want_out=True, out_dtype=out_dtype, prep=prep,
+                             assume_served=served)
+        if not served:
+            verdict.note(prep, key)
+        return res
 
     def serves_prepared(self, x: torch.Tensor) -> bool:
         """binary occupancy and a 9 x 9 x 9 bank: the z-walk kernel behind sn_conv_bank_prepared"""
@@ -351,11 +378,12 @@ class SceneNet(nn.Module):
                     # what the reference feeds is f64 {0., 1.} (ToFullDense): a device-side check routes such grids
                     # to the int8 kernels and anything else to the fp32 contraction, without a host sync
                     return _hip.forward_auto(x.contiguous(), bank, lam)[0]
-            prep = None
             if self.serves_prepared(x):   # the per-bank work of the int8 contraction once, fused into the bank builder
                 bank, prep = self.compute_bank_prepared(x.device)
-            act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
-                                      out_dtype=out_dtype, prep=prep)
+                act, out = self.contract_prepared(x.contiguous(), bank, lam, prep, return_bank_activations, out_dtype)
+            else:
+                act, out = _hip.conv_bank(x.contiguous(), bank, lam, want_act=return_bank_activations, want_out=True,
+                                          out_dtype=out_dtype)
         return (out, act) if return_bank_activations else out
 
 

@@ -246,3 +246,45 @@ def test_all_positive_and_zero_mean_banks_agree_in_every_int8_kernel(hip_device)
             assert torch.equal(a, a0) and torch.equal(o, o0), (name, k)
         assert (o0.cpu().double() - ref_out).abs().max().item() < TOL, name
         assert (a0.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item()), name
+
+
+def test_verdict_is_learnt_without_a_sync_and_the_fallback_launch_left_out(hip_device):
+    """SceneNet.contract_prepared: the first calls run with the fallback launch behind the walk and enqueue an asynchronous
+    read-back of the verdict; once that has landed, calls with the SAME parameters use sn_conv_bank_prepared_served (no
+    fallback launch) and give the same bits; a parameter change starts over; a bank the walk does not serve never loses its
+    fallback."""
+    from scene_net_amd.synthetic import synthetic_tile
+    model = _bench_model(hip_device)
+    model.fused_forward = False
+    tiles = [synthetic_tile(i, 30_000)[0] for i in range(2)]
+    occ = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles, device=hip_device), (64,) * 3, occ_dtype=torch.bool).occ
+    with torch.no_grad():
+        first = model(occ)
+        verdict = model.__dict__["_prepared_verdict"]
+        assert verdict._state == 1                                  # read-back enqueued, nothing waited for
+        torch.cuda.synchronize()
+        second = model(occ)                                         # learns "served" here, launches without the fallback
+        assert verdict._state == 2
+        third = model(occ)
+        assert torch.equal(first, second) and torch.equal(first, third)
+        # an in-place parameter change (what an optimiser step is) invalidates the knowledge
+        model.geneos["cy_0"].geneo_params["radius"].add_(0.25)
+        changed = model(occ)
+        assert verdict._state == 1 and not torch.equal(changed, first)
+        torch.cuda.synchronize()
+    # a bank over the quantisation tolerance: verdict 1, never "served" -- and the result is the fp32 kernel's
+    wide = _symmetric_bank(16, 3, scale=torch.full((16,), 40.0)).to(hip_device)
+    lam = ((torch.rand(16) - 0.3) / 16).to(hip_device)
+    prep = _hip.conv_bank_prep(wide)
+    out = _hip.conv_bank(occ, wide, lam, prep=prep)[1]
+    torch.cuda.synchronize()
+    assert _hip.prep_verdicts(prep).cpu().tolist() == [1]
+    assert torch.equal(out, _hip.conv_bank(occ.view(torch.uint8), wide, lam)[1])
+    # what a caller who assumed wrongly would see: the verdict, and nothing written
+    canary = torch.full_like(out, -7.0)
+    load = _hip.load()
+    rc = load.sn_conv_bank_prepared_served(occ.data_ptr(), _hip.SN_OCC8, wide.data_ptr(), lam.data_ptr(), prep.data_ptr(),
+                                           2, 64, 64, 64, 16, 9, 9, 9, None, canary.data_ptr(), _hip.SN_F32,
+                                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0 and _hip.prep_verdicts(prep).cpu().tolist() == [1] and bool((canary == -7.0).all())
