@@ -1,7 +1,7 @@
-# Round evidence, one call on the GPU box:  bash tools/round_run.sh r02   ->  gpurun_out/<tag>/...
+# Round evidence, one call on the GPU box:  bash tools/round_run.sh r03   ->  gpurun_out/<tag>/...
 # (rocprofv3 is given the program itself after `--`; counters run in their own passes, never with trace domains)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -21,6 +21,10 @@ python3 tools/train_step_bench.py --graph --iters 20 --bf16 > $O/train_bench_bf1
 python tools/c4_bench.py --batch 32 > $O/c4.txt 2>&1 || true
 python tools/c4_bench.py --batch 32 --voxel-size 0.9 0.9 0.9 >> $O/c4.txt 2>&1 || true   # (0.9 m: the ~100 m scans fit 128^3)
 python tools/conv_ab.py --rounds 3 > $O/conv_ab.txt 2>&1 || true
+python tools/step_host_profile.py > $O/step_host.txt 2>&1 || true
+python tools/k1_time.py > $O/k1_time.txt 2>&1 || true
+# the z-walk's hand-over protocol under repetition (a race would show as a wrong bit or a spin timeout, intermittently)
+for i in 1 2 3 4 5; do python -m pytest tests/test_gpu_conv_zwalk.py -q -p no:cacheprovider 2>&1 | tail -1; done > $O/zwalk_repeat.txt
 # PMC passes
 mkdir -p $O/pmc
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES -d $O/pmc/g1 --output-format csv -- python3 tools/profile_path.py --iters 3 --train > $O/pmc/g1.log 2>&1

@@ -20,7 +20,7 @@ out = {"_note": f"HBM-side bytes per launch at BASELINE C2 (32 tiles), from sepa
 for k, v in old.items():
     if k != "_note":
         out[k] = v
-for k in ("conv_occ_i8f_kernel", "conv_occ_i8s_kernel", "conv_occ_i8_kernel", "conv_bank_kernel", "conv_lin_i8_kernel"):
+for k in ("conv_occ_i8z_kernel", "conv_occ_i8f_kernel", "conv_occ_i8s_kernel", "conv_occ_i8_kernel", "conv_bank_kernel", "conv_lin_i8_kernel"):
     if k in kb and (kb[k].get("WRITE_SIZE", 0.0) > 0 or k not in out):
         out[k] = byt(k)
 if all(k in kb for k in vox[:3]):
