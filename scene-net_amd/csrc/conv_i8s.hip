@@ -1554,7 +1554,7 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     if (lds > (size_t)kMaxLds || lds_fb > (size_t)kMaxLds) return 1;
 #define SN_LAUNCH_I8Z(OT, KH, KR, KW)                                                                            \
     do {                                                                                                         \
-        auto kern = conv_occ_i8z_kernel<OT, KH, KR, KW>;                                                         \
+        auto kern = act ? conv_occ_i8z_kernel<OT, KH, KR, KW, true> : conv_occ_i8z_kernel<OT, KH, KR, KW, false>; \
         if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
             return check_launch("sn_conv_bank_prepared(i8z: hipFuncSetAttribute)");                              \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, stream, x, lambdas, (const uint8_t*)prep, z,       \
