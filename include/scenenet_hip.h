@@ -361,6 +361,17 @@ int sn_conv_corr_blocks(int B, int Z, int X, int Y);
 int sn_conv_corr_t(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X, int Y,
                    int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream);
 
+/* The same behind ONE caller-owned workspace of sn_conv_corr_ws_bytes(...) bytes (256-byte aligned), and the entry point
+ * that serves binary occupancy (x_dtype SN_OCC8) as a GATHER over the set voxels (K4s, csrc/corr.hip: a list kernel +
+ * a gather kernel; no matrix core; nnz x kz kx ky terms instead of V x kz x 256 products): the workspace then also holds
+ * the voxel lists.  Any other input, option "corr_dense" = 1, or a workspace with room for the partial rows only
+ * (>= sn_conv_corr_blocks x kz kx ky floats) takes sn_conv_corr_t's kernels.  Both forms sum in a fixed order
+ * (bit-reproducible per form; the two forms differ by fp32 summation order).  Option "corr_sparse_tile_bytes"
+ * (0 = 2048): input bytes per gather job. */
+size_t sn_conv_corr_ws_bytes(int x_dtype, int B, int Z, int X, int Y, int kz, int kx, int ky);
+int sn_conv_corr_ws(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,
+                    int Y, int kz, int kx, int ky, void* ws, size_t ws_bytes, float* C, sn_stream_t stream);
+
 /* Generator Jacobians: dparams [G, SN_NPARAM] f32 = d<dW, bank(params)>/dparams for dW [G,kz,kx,ky] f32
  * (apex has no gradient: it is truncated to an index, arrow.py:235, and non-trainable, arrow.py:134). */
 int sn_geneo_bank_bwd(const float* params, const int32_t* kinds, int G, int kz, int kx, int ky,

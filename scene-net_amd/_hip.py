@@ -63,6 +63,8 @@ SYMBOLS = {
     "sn_conv_corr": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_t": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "sn_conv_corr_blocks": (c_int, [_I, _I, _I, _I]),
+    "sn_conv_corr_ws_bytes": (ctypes.c_size_t, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "sn_conv_corr_ws": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P, _P]),
     "sn_geneo_bank_lambdas": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "sn_geneo_bank_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sn_geneo_backward": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
@@ -685,20 +687,21 @@ def grid_to_points(grid: torch.Tensor, origin=None, voxel_size=None) -> torch.Te
 
 @_on_tensor_device
 def conv_corr(x: torch.Tensor, gout: torch.Tensor, out: Optional[torch.Tensor], kernel_size: Sequence[int]):
-    """C [kz,kx,ky] f32 = sum_{b,v} delta[b,v] x[b, v+t-p]  (sn_conv_corr_t); gout/out [B,1,Z,X,Y] both f32 or both
-    bf16 (bf16 activation storage: the products are formed and summed in fp32 either way)."""
+    """C [kz,kx,ky] f32 = sum_{b,v} delta[b,v] x[b, v+t-p]  (sn_conv_corr_ws: bool input as the gather over the set
+    voxels, anything else as the GEMM); gout/out [B,1,Z,X,Y] both f32 or both bf16 (bf16 activation storage: the products
+    are formed and summed in fp32 either way)."""
     B, _, Z, X, Y = x.shape
     kz, kx, ky = (int(k) for k in kernel_size)
     if gout.dtype not in (torch.float32, torch.bfloat16):
         raise HipLibraryError(f"gout must be float32 or bfloat16 (got {gout.dtype})")
     if out is not None and out.dtype != gout.dtype:
         raise HipLibraryError(f"out ({out.dtype}) and gout ({gout.dtype}) must have the same dtype")
-    nblk = load().sn_conv_corr_blocks(B, Z, X, Y)
-    ws = torch.empty((nblk, kz * kx * ky), dtype=torch.float32, device=x.device)
+    nbytes = int(load().sn_conv_corr_ws_bytes(_DT[x.dtype], B, Z, X, Y, kz, kx, ky))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)   # (torch's allocator: 512-byte aligned)
     C = torch.empty((kz, kx, ky), dtype=torch.float32, device=x.device)
-    rc = load().sn_conv_corr_t(_ptr(x, None, "x"), _DT[x.dtype], _ptr(gout, None, "gout"), _ptr(out, None, "out"),
-                               _DT[gout.dtype], B, Z, X, Y, kz, kx, ky, _ptr(ws), _ptr(C), _stream())
-    _check(rc, "sn_conv_corr")
+    rc = load().sn_conv_corr_ws(_ptr(x, None, "x"), _DT[x.dtype], _ptr(gout, None, "gout"), _ptr(out, None, "out"),
+                                _DT[gout.dtype], B, Z, X, Y, kz, kx, ky, _ptr(ws), nbytes, _ptr(C), _stream())
+    _check(rc, "sn_conv_corr_ws")
     return C
 
 

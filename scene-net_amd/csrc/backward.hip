@@ -13,6 +13,9 @@
 namespace sn {  // corr.hip
 int corr_mfma_supported(int kz, int kx, int ky);
 int corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky);
+size_t corr_sparse_ws_bytes(int x_dtype, int B, int Z, int X, int Y, int kz, int kx, int ky);
+int corr_sparse_launch(const void* x, const void* gout, const void* out, int g_dtype, int B, int Z, int X, int Y, int kz,
+                       int kx, int ky, void* ws, float* C, hipStream_t s);
 int corr_mfma_launch(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,
                      int Y, int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
 }  // namespace sn
@@ -314,6 +317,33 @@ extern "C" int sn_conv_corr_t(const void* x, int x_dtype, const void* gout_v, co
 extern "C" int sn_conv_corr(const void* x, int x_dtype, const float* gout, const float* out, int B, int Z, int X,
                             int Y, int kz, int kx, int ky, float* partial_ws, float* C, sn_stream_t stream) {
     return sn_conv_corr_t(x, x_dtype, gout, out, SN_F32, B, Z, X, Y, kz, kx, ky, partial_ws, C, stream);
+}
+
+extern "C" size_t sn_conv_corr_ws_bytes(int x_dtype, int B, int Z, int X, int Y, int kz, int kx, int ky) {
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || kz <= 0 || kx <= 0 || ky <= 0) return 0;
+    const size_t rows = (size_t)sn_conv_corr_blocks(B, Z, X, Y) * kz * kx * ky * sizeof(float);
+    const size_t sparse = sn::corr_sparse_ws_bytes(x_dtype, B, Z, X, Y, kz, kx, ky);
+    return sparse > rows ? sparse : rows;
+}
+
+extern "C" int sn_conv_corr_ws(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z,
+                               int X, int Y, int kz, int kx, int ky, void* ws, size_t ws_bytes, float* C,
+                               sn_stream_t stream) {
+    if (!x || !gout || !ws || !C) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr_ws: null pointer");
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr_ws: non-positive extent");
+    if (g_dtype != SN_F32 && g_dtype != SN_BF16)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr_ws: g_dtype %d (SN_F32 | SN_BF16)", g_dtype);
+    const size_t rows = (size_t)sn_conv_corr_blocks(B, Z, X, Y) * kz * kx * ky * sizeof(float);
+    if (ws_bytes < rows)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_corr_ws: workspace of %zu bytes, %zu needed (sn_conv_corr_ws_bytes)",
+                        ws_bytes, rows);
+    // binary occupancy: the gather over the set voxels (corr.hip, K4s) unless "corr_dense" asks for the GEMM form or the
+    // caller's workspace has no room for the lists
+    const size_t sparse = sn::corr_sparse_ws_bytes(x_dtype, B, Z, X, Y, kz, kx, ky);
+    if (sparse && ws_bytes >= sparse)
+        return sn::corr_sparse_launch(x, gout, out, g_dtype, B, Z, X, Y, kz, kx, ky, ws, C, sn::as_stream(stream));
+    return sn_conv_corr_t(x, x_dtype, gout, out, g_dtype, B, Z, X, Y, kz, kx, ky, (float*)ws, C, stream);
 }
 
 extern "C" int sn_conv_corr_blocks(int B, int Z, int X, int Y) {

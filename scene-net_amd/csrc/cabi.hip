@@ -27,6 +27,8 @@ int option_conv_i8_legacy() {
 }
 static std::atomic<int> g_i8z_variant{2};
 int option_conv_i8z_variant() { return g_i8z_variant.load(std::memory_order_relaxed); }
+static std::atomic<int> g_corr_tile_bytes{0};
+int option_corr_sparse_tile_bytes() { return g_corr_tile_bytes.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8_fold{-1};   // -1: not looked at yet; SN_CONV_I8_NOFOLD=1 in the environment starts it at 0
 int option_conv_i8_fold() {
     int v = g_i8_fold.load(std::memory_order_relaxed);
@@ -49,7 +51,8 @@ struct ExtraOpt {
 ExtraOpt g_extra[kOptCount] = {{"conv_no_i8", "SN_CONV_NO_I8", {-1}},
                                {"conv_double_buffer", "SN_CONV_DOUBLE_BUFFER", {-1}},
                                {"conv_lin_no24", "SN_CONV_LIN_NO24", {-1}},
-                               {"conv_i8_no_stage", "SN_CONV_I8_NO_STAGE", {-1}}};
+                               {"conv_i8_no_stage", "SN_CONV_I8_NO_STAGE", {-1}},
+                               {"corr_dense", "SN_CORR_DENSE", {-1}}};
 }  // namespace
 int option_extra(ExtraOption which) {
     ExtraOpt& o = g_extra[which];
@@ -161,6 +164,12 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_i8z_variant.store(value, std::memory_order_relaxed);
         return SN_OK;
     }
+    if (strcmp(name, "corr_sparse_tile_bytes") == 0) {
+        if (value < 0 || value > 2048)
+            return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: corr_sparse_tile_bytes is 0 (default: 2048) .. 2048");
+        sn::g_corr_tile_bytes.store(value, std::memory_order_relaxed);
+        return SN_OK;
+    }
     for (auto& o : sn::g_extra)
         if (strcmp(name, o.name) == 0) {
             o.value.store(value ? 1 : 0, std::memory_order_relaxed);
@@ -175,6 +184,7 @@ extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_i8_legacy") == 0) return sn::option_conv_i8_legacy();
     if (name && strcmp(name, "conv_i8_fold") == 0) return sn::option_conv_i8_fold();
     if (name && strcmp(name, "conv_i8z_variant") == 0) return sn::option_conv_i8z_variant();
+    if (name && strcmp(name, "corr_sparse_tile_bytes") == 0) return sn::option_corr_sparse_tile_bytes();
     if (name)
         for (int i = 0; i < sn::kOptCount; ++i)
             if (strcmp(name, sn::g_extra[i].name) == 0) return sn::option_extra((sn::ExtraOption)i);

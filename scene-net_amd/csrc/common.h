@@ -29,6 +29,7 @@ inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_
 int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 int option_conv_i8_fold();            // cabi.hip (sn_set_option "conv_i8_fold", default 1): 0 = never try the folded int8 kernel (conv_i8s.hip)
 int option_conv_i8z_variant();        // cabi.hip (sn_set_option "conv_i8z_variant"): shape of the z-walk kernel's rounds (conv_i8z.inc)
+int option_corr_sparse_tile_bytes();  // cabi.hip (sn_set_option "corr_sparse_tile_bytes"): input bytes per job of the sparse correlation (0: 2048, the maximum)
 int option_conv_i8_legacy();          // cabi.hip (sn_set_option "conv_i8_legacy"): 1 = the four-copy kernel of conv_i8.hip for every shape
 
 // hipFuncAttributeMaxDynamicSharedMemorySize, set once per kernel (and raised when a launch needs more): the
@@ -67,6 +68,7 @@ enum ExtraOption {
     kOptConvDoubleBuffer,    // "conv_double_buffer" SN_CONV_DOUBLE_BUFFER=1 fp32 kernel: double-buffered 4x4x64 tiles
     kOptConvLinNo24,         // "conv_lin_no24"     SN_CONV_LIN_NO24=1      K3L: 32-byte instead of 24-byte kernel rows
     kOptConvI8NoStage,       // "conv_i8_no_stage"  SN_CONV_I8_NO_STAGE=1   four-copy kernel without the LDS-DMA staging
+    kOptCorrDense,           // "corr_dense"        SN_CORR_DENSE=1         backward correlation of binary occupancy as the GEMM (K4) instead of the gather (K4s)
     kOptCount
 };
 int option_extra(ExtraOption which);   // cabi.hip

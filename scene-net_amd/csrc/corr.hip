@@ -25,6 +25,9 @@ int corr_mfma_supported(int kz, int kx, int ky);
 int corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky);
 int corr_mfma_launch(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,
                      int Y, int kz, int kx, int ky, float* partial_ws, float* C, hipStream_t s);
+size_t corr_sparse_ws_bytes(int x_dtype, int B, int Z, int X, int Y, int kz, int kx, int ky);
+int corr_sparse_launch(const void* x, const void* gout, const void* out, int g_dtype, int B, int Z, int X, int Y, int kz,
+                       int kx, int ky, void* ws, float* C, hipStream_t s);
 }  // namespace sn
 
 namespace {
@@ -273,7 +276,9 @@ __global__ __launch_bounds__(kThreads, KZMAX <= 9 ? 6 : 4) void corr_mfma_kernel
     }
 }
 
-// C[t] = sum_k partial[k][t]: one wave per tap, lanes stride the rows, xor-tree at the end (fixed order)
+// C[t] = sum_k partial[k][t]: one wave per tap, lanes stride the rows, xor-tree at the end (fixed order).  ([measured] 5.6 us
+// for 768 x 729; a coalesced form -- 32 taps per workgroup, 16 row chunks per tap, 23 workgroups -- took 14.5 us: too few
+// waves to cover the latency of 48 dependent-free but serial loads each.)
 __global__ __launch_bounds__(256) void corr_rows_reduce_kernel(const float* __restrict__ partial, int nrows, int ntaps,
                                                                float* __restrict__ C) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -313,6 +318,369 @@ bool plan(int B, int Z, int X, int Y, int kz, int kx, int ky, CorrShape* s, size
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------- K4s: sparse gather
+// The same correlation for BINARY OCCUPANCY (SN_OCC8), read the other way round:
+//     C[dz,dx,dy] = sum over the SET voxels (b, z', x', y') of  delta[b, z'-dz+pz, x'-dx+px, y'-dy+py]
+// A LiDAR tile sets 1-4 % of its voxels ([measured] the synthetic C2 tiles: 9.2 k of 262 k), so the sum has
+// nnz x 729 terms where the GEMM above executes V x 9 x 256 products and then skips the K steps that are all zero.
+// No matrix core is involved: the work is LDS reads and fp32 adds.
+//
+// Two launches.  corr_lists_kernel turns every (b, z', tile of TXR input rows; TXR Y <= 2048) into a LIST of its set
+// voxels -- 16-bit byte offsets of the voxel's cell in the gather's delta tile, in memory order (a wave scan + wave
+// totals, no atomics: the order, hence every fp32 sum, is the same in every run), padded with entries that read zeros.
+// corr_gather_kernel's job = (b, delta plane z, tile): the delta rows the tile's taps can reach are staged once, with the
+// relu(tanh) derivative fused, into a zero-haloed LDS tile of row pitch P = ky (mod 64) -- the 64 taps a wave reads for
+// one voxel fall into 64 different banks -- and the kz lists of the planes z + dz - pz are copied beside it.  Thread
+// (group g, tap (dx, dy)) adds delta[cell - (dx P + dy)] over every (groups)-th quad of list dz into its accumulator for
+// dz; 512 / (kx ky) groups walk a list side by side.  The next job's global loads (delta, forward output, list chunk) are
+// issued before the gather and consumed after it.  Accumulators persist over a persistent workgroup's jobs; groups,
+// then workgroups, are summed in a fixed order.
+// ([measured] C2, 32 tiles: lists built inside the gather kernel -- every plane compacted by the nine jobs that read it,
+// ~2000 instructions per wave and job around a gather of ~400 -- took 102-106 us in two variants, no better than the
+// GEMM form's 96; bound by instruction issue, not by LDS or HBM.)
+constexpr int kSpThreads = 512;
+constexpr int kSpStage = 6;        // delta elements per thread and job (DR Y <= 6 x 512)
+constexpr int kSpListThreads = 256;   // corr_lists_kernel: 8 tile bytes per thread
+
+struct SparseShape {
+    int B, Z, X, Y, kz, kx, ky, pz, px, py;
+    int TXR, nxt, njobs;
+    int DR;            // delta rows staged per job: TXR + kx - 1
+    int P;             // row pitch of the delta tile (floats)
+    int dl_floats;     // delta tile + a zero tail of (kx - 1) P + ky floats (what a padding entry's taps read), rounded to 4
+    int T, groups;     // taps per plane, voxel groups
+    int capP;          // entries per list (TXR Y + padding; a multiple of 8)
+    int vec;           // list kernel: a thread's 8 input bytes are one aligned load and lie in one row
+    unsigned y_magic;  // e / Y == mulhi(e, y_magic) for every e the kernels form (checked on the host)
+    unsigned nxt_magic, b_magic;   // likewise job / nxt and (job / nxt) / B for every job index
+    int dbg;           // wrong-result timing switch (SN_CONV_DEBUG builds only: SN_K4S_SKIP): 1 no job does anything
+};
+
+// list index of (b, z', tile xt); the gather reads the lists of z' = z + dz - pz
+__device__ __forceinline__ int list_index(const SparseShape& s, int b, int z, int xt) { return (b * s.Z + z) * s.nxt + xt; }
+
+__global__ __launch_bounds__(kSpListThreads) void corr_lists_kernel(const uint8_t* __restrict__ x, SparseShape s,
+                                                                     uint16_t* __restrict__ lists,
+                                                                     int* __restrict__ counts) {
+    __shared__ int wtot[kSpListThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = blockIdx.x;
+    const int xt = li % s.nxt, bz = li / s.nxt;
+    const int x0 = xt * s.TXR;
+    const int nrows = (s.X - x0 < s.TXR) ? s.X - x0 : s.TXR;
+    const int nbytes = nrows * s.Y;
+    const uint8_t* src = x + (size_t)bz * s.X * s.Y + (size_t)x0 * s.Y + 8 * tid;
+    uint32_t w0 = 0u, w1 = 0u;
+    if (s.vec) {
+        if (8 * tid < nbytes) {
+            const uint2 v = *reinterpret_cast<const uint2*>(src);
+            w0 = v.x; w1 = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (8 * tid + k < nbytes) w0 |= (uint32_t)src[k] << (8 * k);
+            if (8 * tid + 4 + k < nbytes) w1 |= (uint32_t)src[4 + k] << (8 * k);
+        }
+    }
+    auto nibble = [](uint32_t w) -> uint32_t {   // bit k: byte k is non-zero
+        uint32_t v = w | (w >> 4);
+        v |= v >> 2;
+        v |= v >> 1;
+        v &= 0x01010101u;
+        return ((v * 0x01020408u) >> 24) & 0xfu;   // bits 0, 8, 16, 24 -> 0, 1, 2, 3
+    };
+    const uint32_t mask = nibble(w0) | (nibble(w1) << 4);
+    const int c = __builtin_popcount(mask);
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kSpListThreads / 64; ++k) {
+        const int t = wtot[k];
+        if (k < wave) base += t;
+        total += t;
+    }
+    uint16_t* list = lists + (size_t)li * s.capP;
+    if (mask) {
+        int pos = base + incl - c;
+        int row = (int)__umulhi((unsigned)(8 * tid), s.y_magic), col = 8 * tid - row * s.Y;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((mask >> k) & 1u) list[pos++] = (uint16_t)(((row + s.kx - 1) * s.P + col + s.ky - 1) * 4);
+            if (++col >= s.Y) { col = 0; ++row; }
+        }
+    }
+    // padding: the last quad of every group's walk is complete; its entries read the zero tail of the tile
+    if (tid < 4 * s.groups) list[total + tid] = (uint16_t)((s.DR * s.P + (s.kx - 1) * s.P + (s.ky - 1)) * 4);
+    // what the gather needs to know: the list's length in ROUNDS (quads per group) -- no division on its side
+    if (tid == 0) counts[li] = (total + 4 * s.groups - 1) / (4 * s.groups);
+}
+
+template <typename DT, int KZMAX>
+__global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __restrict__ gout, const DT* __restrict__ out,
+                                                                     const uint16_t* __restrict__ lists,
+                                                                     const int* __restrict__ counts, SparseShape s,
+                                                                     float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dl = lds;
+    uint16_t* ll = reinterpret_cast<uint16_t*>(dl + s.dl_floats);   // the job's kz lists, back to back (padded lengths)
+    const int tid = threadIdx.x;
+    const size_t plane = (size_t)s.X * s.Y;
+    const int grp = tid / s.T, tap = tid - grp * s.T;
+    const bool gathers = grp < s.groups;   // (the threads past the last group walk group 0's quads; their sums are dropped)
+    const int tdx = tap / s.ky, tdy = tap - tdx * s.ky;
+    // a voxel's cell is (row rr + kx - 1, column y + ky - 1) of the tile; tap (dx, dy) reads dx rows and dy columns before it
+    const char* const tap_base = reinterpret_cast<const char*>(dl) - (tdx * s.P + tdy) * 4;
+    const int quad = 4 * s.groups;   // list lengths are padded to this: every group runs the same number of rounds
+    const uint16_t* const my_quads = ll + 4 * (gathers ? grp : 0);
+
+    float acc[KZMAX];
+#pragma unroll
+    for (int i = 0; i < KZMAX; ++i) acc[i] = 0.f;
+    for (int i = tid; i < s.dl_floats; i += kSpThreads) dl[i] = 0.f;   // halo columns and the tail stay zero for good
+
+    struct Job { int b, z, xt, e_lo; };   // delta element e of the tile is grid element e_lo + e of plane (b, z)
+    auto decode = [&](int job) -> Job {
+        // z-major, batch fastest: a persistent workgroup's jobs fall on different z (the ground planes hold most set voxels)
+        Job r;
+        const int j = s.nxt_magic ? (int)__umulhi((unsigned)job, s.nxt_magic) : job;   // (magic 0: divisor 1)
+        r.xt = job - j * s.nxt;
+        r.z = s.b_magic ? (int)__umulhi((unsigned)j, s.b_magic) : j;
+        r.b = j - r.z * s.B;
+        r.e_lo = (r.xt * s.TXR - (s.kx - 1 - s.px)) * s.Y;   // rows are whole: (q0 + rr) Y + y = q0 Y + e
+        return r;
+    };
+    // a job's list lengths in rounds (wave-uniform: scalar loads); list dz is list_index(b, z - pz, xt) + dz nxt
+    auto list_counts = [&](const Job& jb, int (&n)[KZMAX]) {
+        const int i0 = list_index(s, jb.b, jb.z - s.pz, jb.xt);
+#pragma unroll
+        for (int dz = 0; dz < KZMAX; ++dz) {
+            const int zp = jb.z + dz - s.pz;
+            n[dz] = (dz < s.kz && zp >= 0 && zp < s.Z) ? counts[i0 + dz * s.nxt] : 0;
+        }
+    };
+    // chunk c (four entries) of the job's lists, from global memory; chunks past the end read as nothing
+    auto load_chunk = [&](const Job& jb, const int (&n)[KZMAX], int c) -> uint2 {
+        int e = 4 * c, dz = 0;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < KZMAX; ++k) {
+            const int len = n[k] * quad;
+            if (!found) {
+                if (e < len) found = true, dz = k;
+                else e -= len;
+            }
+        }
+        uint2 v = make_uint2(0u, 0u);
+        if (found) {
+            const int idx = list_index(s, jb.b, jb.z - s.pz, jb.xt) + dz * s.nxt;
+            v = *reinterpret_cast<const uint2*>(lists + (size_t)idx * s.capP + e);
+        }
+        return v;
+    };
+    auto issue_delta = [&](const Job& jb, float (&g)[kSpStage], float (&o)[kSpStage]) {
+        const size_t dbase = ((size_t)jb.b * s.Z + jb.z) * plane;
+        const int nel = s.DR * s.Y, e_hi = s.X * s.Y;
+#pragma unroll
+        for (int u = 0; u < kSpStage; ++u) {
+            const int e = u * kSpThreads + tid;
+            const int ge = jb.e_lo + e;
+            g[u] = 0.f; o[u] = 1.f;
+            if (e < nel && ge >= 0 && ge < e_hi) {
+                g[u] = (float)gout[dbase + ge];
+                if (out) o[u] = (float)out[dbase + ge];
+            }
+        }
+    };
+
+    // Software pipeline over the workgroup's jobs: the list lengths are fetched two jobs ahead (the chunk addresses depend
+    // on them), delta / output / list chunk one job ahead -- issued before a gather, consumed after it.
+    float g[kSpStage], o[kSpStage];
+    int n[KZMAX], nn[KZMAX];
+    uint2 chunk = make_uint2(0u, 0u);
+    int job = blockIdx.x;
+    Job cur = decode(job < s.njobs ? job : 0), nxt = cur;
+#pragma unroll
+    for (int dz = 0; dz < KZMAX; ++dz) n[dz] = nn[dz] = 0;
+    if (job < s.njobs) {
+        list_counts(cur, n);
+        issue_delta(cur, g, o);
+        chunk = load_chunk(cur, n, tid);
+        if (job + (int)gridDim.x < s.njobs) {
+            nxt = decode(job + gridDim.x);
+            list_counts(nxt, nn);
+        }
+    }
+    for (; job < s.njobs; job += gridDim.x) {
+        int rounds[KZMAX], total = 0;
+#pragma unroll
+        for (int dz = 0; dz < KZMAX; ++dz) rounds[dz] = n[dz], total += n[dz];
+        const bool work = total > 0 && !(s.dbg & 1);   // no set voxel in reach of this delta tile: nothing to add
+        if (work) {
+            __syncthreads();   // the previous job's gathers are done with the delta tile and the lists
+            // ---- delta tile: rows q0 .. q0 + DR - 1 (zero outside the grid), columns ky - 1 - py + y
+            const int nel = s.DR * s.Y;
+#pragma unroll
+            for (int u = 0; u < kSpStage; ++u) {
+                const int e = u * kSpThreads + tid;
+                if (e < nel) {
+                    const int rr = (int)__umulhi((unsigned)e, s.y_magic), y = e - rr * s.Y;
+                    float d = g[u];
+                    if (out) d = (o[u] > 0.f) ? d * (1.f - o[u] * o[u]) : 0.f;
+                    dl[rr * s.P + (s.ky - 1 - s.py) + y] = d;
+                }
+            }
+            // ---- the lists: chunk tid came with the prefetch; a job with more than 512 chunks fetches the rest now
+            const int nchunks = total * s.groups;
+            if (tid < nchunks) *reinterpret_cast<uint2*>(ll + 4 * tid) = chunk;
+            for (int c = tid + kSpThreads; c < nchunks; c += kSpThreads)
+                *reinterpret_cast<uint2*>(ll + 4 * c) = load_chunk(cur, n, c);
+            __syncthreads();
+        }
+        // ---- the next job's loads fly during the gather
+        const int next = job + gridDim.x;
+        if (next < s.njobs) {
+            cur = nxt;
+#pragma unroll
+            for (int dz = 0; dz < KZMAX; ++dz) n[dz] = nn[dz];
+            issue_delta(cur, g, o);
+            chunk = load_chunk(cur, n, tid);
+            if (next + (int)gridDim.x < s.njobs) {
+                nxt = decode(next + gridDim.x);
+                list_counts(nxt, nn);
+            }
+        }
+        if (work) {
+            // every thread of a wave runs the same rounds (uniform trip counts: scalar loop control); the entries of the
+            // next round are requested before this round's four reads
+            const uint16_t* q = my_quads;
+#pragma unroll
+            for (int dz = 0; dz < KZMAX; ++dz) {
+                if (dz >= s.kz) continue;
+                const int nr = rounds[dz];
+                if (nr == 0) continue;
+                float a = acc[dz];
+                uint2 e = *reinterpret_cast<const uint2*>(q);
+                for (int r = 0; r < nr; ++r) {
+                    q += quad;
+                    const uint2 en = *reinterpret_cast<const uint2*>(q);   // (one quad past the last list: slack in `ll`)
+                    const float v0 = *reinterpret_cast<const float*>(tap_base + (e.x & 0xffffu));
+                    const float v1 = *reinterpret_cast<const float*>(tap_base + (e.x >> 16));
+                    const float v2 = *reinterpret_cast<const float*>(tap_base + (e.y & 0xffffu));
+                    const float v3 = *reinterpret_cast<const float*>(tap_base + (e.y >> 16));
+                    a += v0; a += v1; a += v2; a += v3;
+                    e = en;
+                }
+                acc[dz] = a;
+            }
+        }
+    }
+
+    // ---- groups add up in order, then the workgroup writes its partial row
+    __syncthreads();
+    float* red = lds;   // [groups][kz][T]
+    if (gathers) {
+#pragma unroll
+        for (int dz = 0; dz < KZMAX; ++dz)
+            if (dz < s.kz) red[(grp * s.kz + dz) * s.T + tap] = acc[dz];
+    }
+    __syncthreads();
+    const int ntaps = s.kz * s.T;
+    float* prow = partial + (size_t)blockIdx.x * ntaps;
+    for (int t = tid; t < ntaps; t += kSpThreads) {
+        float a = red[t];
+        for (int gq = 1; gq < s.groups; ++gq) a += red[gq * ntaps + t];
+        prow[t] = a;
+    }
+}
+
+// u / d == mulhi(u, magic) for all 0 <= u <= umax?  magic = floor(2^32 / d) + 1, checked exhaustively (umax is at most a
+// few million); d = 1 has no such multiplier: magic 0 stands for "the quotient is u" (div_magic below).
+bool division_magic_u(unsigned d, unsigned umax, unsigned& magic) {
+    if (d == 1) {
+        magic = 0u;
+        return true;
+    }
+    magic = (unsigned)((((unsigned long long)1 << 32) / d) + 1ull);
+    for (unsigned long long u = 0; u <= umax; ++u)
+        if ((unsigned)((u * magic) >> 32) != (unsigned)(u / d)) return false;
+    return true;
+}
+
+struct SparsePlan {
+    SparseShape s;
+    size_t lds_bytes;
+    int grid;          // gather workgroups = partial rows
+    int nlists;        // B Z nxt
+    size_t off_counts, off_lists, ws_bytes;   // workspace: [grid x ntaps floats | nlists ints | nlists x capP uint16]
+};
+
+bool plan_sparse(int B, int Z, int X, int Y, int kz, int kx, int ky, int tile_bytes, SparsePlan* p) {
+    SparseShape* s = &p->s;
+    const int KZMAX = kz <= 9 ? 9 : 16;
+    if (kz > 16 || kx * ky > kSpThreads || Y > 8 * kSpListThreads) return false;
+    s->B = B; s->Z = Z; s->X = X; s->Y = Y; s->kz = kz; s->kx = kx; s->ky = ky;
+    s->pz = (kz - 1) / 2; s->px = (kx - 1) / 2; s->py = (ky - 1) / 2;
+    s->T = kx * ky;
+    s->groups = kSpThreads / s->T;
+    // input rows per job: 8 bytes per thread of the list kernel at most, and the delta rows they reach must be kSpStage
+    // elements per thread of the gather
+    int cap_bytes = tile_bytes > 0 ? tile_bytes : 8 * kSpListThreads;
+    if (cap_bytes > 8 * kSpListThreads) cap_bytes = 8 * kSpListThreads;
+    int txr = cap_bytes / Y;
+    if (txr < 1) txr = 1;
+    if (txr > X) txr = X;
+    while (txr > 1 && (txr + kx - 1) * Y > kSpStage * kSpThreads) --txr;
+    if ((txr + kx - 1) * Y > kSpStage * kSpThreads) return false;
+    s->TXR = txr;
+    s->nxt = (X + txr - 1) / txr;
+    s->DR = txr + kx - 1;
+    int P = Y + ky - 1;
+    while (P % 64 != ky % 64) ++P;
+    s->P = P;
+    s->dl_floats = (s->DR * P + (kx - 1) * P + ky + 3) / 4 * 4;
+    if ((size_t)s->dl_floats * 4 > 65535) return false;   // list entries are 16-bit byte offsets into the tile
+    const int quad = 4 * s->groups;
+    s->capP = ((txr * Y + quad - 1) / quad * quad + quad + 7) / 8 * 8;
+    const long long njobs = (long long)B * Z * s->nxt;
+    if (njobs > 0x7fffffff / 2 || (long long)B * Z * X * Y > 0x7fffffff) return false;
+    s->njobs = (int)njobs;
+    size_t body = (size_t)s->dl_floats * 4 + (size_t)KZMAX * s->capP * 2 + (size_t)quad * 2 + 16;   // (+ the quad the last round requests ahead)
+    const size_t red = (size_t)s->groups * kz * s->T * 4;   // the groups' sums at the end reuse the tile and the lists
+    if (red > body) body = red;
+    const size_t need = (body + 15) / 16 * 16;
+    if (need > 150 * 1024) return false;
+    p->lds_bytes = need;
+    // e / Y by multiplication for every e the kernels divide: e < kSpStage x 512 (staging), 8 x 256 (lists)
+    const unsigned emax = (unsigned)(kSpStage * kSpThreads + 8 * kSpListThreads);
+    s->y_magic = (unsigned)((((unsigned long long)1 << 32) / (unsigned)Y) + 1ull);
+    for (unsigned e = 0; e <= emax; ++e)
+        if ((unsigned)(((unsigned long long)e * s->y_magic) >> 32) != e / (unsigned)Y) return false;
+    unsigned um;
+    if (!division_magic_u((unsigned)s->nxt, (unsigned)s->njobs, um)) return false;
+    s->nxt_magic = um;
+    if (!division_magic_u((unsigned)B, (unsigned)(s->njobs / s->nxt + 1), um)) return false;
+    s->b_magic = um;
+    const int per_cu = (int)((160 * 1024) / need);
+    const int cap = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));   // <= 768 rows
+    p->grid = s->njobs < cap ? s->njobs : cap;
+    p->nlists = s->njobs;
+    const size_t ntaps = (size_t)kz * kx * ky;
+    p->off_counts = ((size_t)p->grid * ntaps * 4 + 255) / 256 * 256;
+    p->off_lists = (p->off_counts + (size_t)p->nlists * 4 + 255) / 256 * 256;
+    p->ws_bytes = p->off_lists + (size_t)p->nlists * s->capP * 2;
+    s->dbg = 0;
+    return true;
+}
+
 }  // namespace
 
 int sn::corr_mfma_supported(int kz, int kx, int ky) { return kz <= 16 && kx <= 16 && ky <= 16; }
@@ -322,6 +690,48 @@ int sn::corr_mfma_rows(int B, int Z, int X, int Y, int kz, int kx, int ky) {
     size_t lds;
     int grid;
     return plan(B, Z, X, Y, kz, kx, ky, &s, &lds, &grid) ? grid : 0;
+}
+
+size_t sn::corr_sparse_ws_bytes(int x_dtype, int B, int Z, int X, int Y, int kz, int kx, int ky) {
+    if (x_dtype != SN_OCC8 || sn::option_extra(sn::kOptCorrDense)) return 0;
+    SparsePlan p;
+    return plan_sparse(B, Z, X, Y, kz, kx, ky, sn::option_corr_sparse_tile_bytes(), &p) ? p.ws_bytes : 0;
+}
+
+int sn::corr_sparse_launch(const void* x, const void* gout, const void* out, int g_dtype, int B, int Z, int X, int Y, int kz,
+                           int kx, int ky, void* ws, float* C, hipStream_t stream) {
+    SparsePlan p;
+    if (!plan_sparse(B, Z, X, Y, kz, kx, ky, sn::option_corr_sparse_tile_bytes(), &p))
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr_ws: shape outside the sparse correlation kernels");
+    SparseShape& s = p.s;
+    s.vec = (Y % 8 == 0) && ((uintptr_t)x % 8 == 0);
+    s.dbg = sn::debug_env_int("SN_K4S_SKIP");
+    float* partial = reinterpret_cast<float*>(ws);
+    int* counts = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + p.off_counts);
+    uint16_t* lists = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(ws) + p.off_lists);
+    hipLaunchKernelGGL(corr_lists_kernel, dim3(p.nlists), dim3(kSpListThreads), 0, stream, (const uint8_t*)x, s, lists,
+                       counts);
+    if (int rc = sn::check_launch("sn_conv_corr_ws(lists)")) return rc;
+#define SN_CORR_SPARSE(DT, KZMAX)                                                                                 \
+    do {                                                                                                          \
+        auto kern = corr_gather_kernel<DT, KZMAX>;                                                                \
+        if (sn::ensure_dynamic_lds((const void*)kern, (int)p.lds_bytes) != hipSuccess)                            \
+            return sn::check_launch("sn_conv_corr_ws(gather: hipFuncSetAttribute)");                              \
+        hipLaunchKernelGGL(kern, dim3(p.grid), dim3(kSpThreads), p.lds_bytes, stream, (const DT*)gout,            \
+                           (const DT*)out, (const uint16_t*)lists, (const int*)counts, s, partial);               \
+    } while (0)
+    if (g_dtype == SN_BF16) {
+        if (kz <= 9) SN_CORR_SPARSE(__bf16, 9);
+        else SN_CORR_SPARSE(__bf16, 16);
+    } else {
+        if (kz <= 9) SN_CORR_SPARSE(float, 9);
+        else SN_CORR_SPARSE(float, 16);
+    }
+#undef SN_CORR_SPARSE
+    if (int rc = sn::check_launch("sn_conv_corr_ws(gather)")) return rc;
+    const int ntaps = kz * kx * ky;
+    hipLaunchKernelGGL(corr_rows_reduce_kernel, dim3((ntaps + 3) / 4), dim3(256), 0, stream, partial, p.grid, ntaps, C);
+    return sn::check_launch("sn_conv_corr_ws(reduce)");
 }
 
 int sn::corr_mfma_launch(const void* x, int x_dtype, const void* gout, const void* out, int g_dtype, int B, int Z, int X,

@@ -85,6 +85,72 @@ def test_correlation_kernel(hip_device):
         assert torch.equal(C1, C2)  # fixed-order reduction
 
 
+@pytest.fixture
+def dense_correlation():
+    """switches binary-occupancy correlations to the GEMM form (K4) and back"""
+    def use(on):
+        _hip.set_option("corr_dense", 1 if on else 0)
+    yield use
+    _hip.set_option("corr_dense", 0)
+    _hip.set_option("corr_sparse_tile_bytes", 0)
+
+
+@pytest.mark.parametrize("shape,ks", [((2, 1, 12, 10, 20), (5, 5, 5)), ((1, 1, 9, 17, 70), (9, 9, 9)),
+                                      ((3, 1, 8, 8, 8), (6, 5, 6)), ((2, 1, 20, 33, 48), (9, 7, 9)),
+                                      ((1, 1, 5, 3, 7), (3, 3, 3)), ((2, 1, 11, 40, 64), (9, 9, 9)),
+                                      ((1, 1, 4, 6, 300), (3, 5, 17))])
+@pytest.mark.parametrize("density", [0.0, 0.03, 0.6, 1.0])
+def test_sparse_correlation_against_conv3d_weight_gradient(hip_device, dense_correlation, shape, ks, density):
+    """K4s -- binary occupancy: the gather over the set voxels -- == the weight gradient of a one-kernel conv3d (fp64, CPU),
+    with and without the fused relu(tanh) derivative; == the GEMM form (K4) within fp32 summation error; every tile size of
+    the gather gives the same numbers up to that error; two runs give the same bits (ragged extents, Y not a multiple of
+    16, kernels of every parity, empty and full grids)."""
+    torch.manual_seed(hash((shape, ks)) % 1000)
+    x = torch.rand(shape) < density
+    g = torch.randn(shape)
+    o = torch.tanh(torch.randn(shape)).clamp_min(0.0)   # a forward output: relu(tanh(.)), zero on half the voxels
+    xd, gd, od = x.to(hip_device), g.to(hip_device).contiguous(), o.to(hip_device).contiguous()
+    for out_cpu, out_dev in ((None, None), (o, od)):
+        delta = g.double() if out_cpu is None else g.double() * (out_cpu.double() > 0) * (1 - out_cpu.double() ** 2)
+        w = torch.zeros((1, 1) + ks, dtype=torch.float64, requires_grad=True)
+        (torch.nn.functional.conv3d(x.double(), w, padding="same") * delta).sum().backward()
+        want = w.grad[0, 0]
+        tol = 2e-4 * max(1.0, want.abs().max().item())
+        dense_correlation(False)
+        got = {}
+        for tile_bytes in (0, 1024, 256):
+            _hip.set_option("corr_sparse_tile_bytes", tile_bytes)
+            got[tile_bytes] = _hip.conv_corr(xd, gd, out_dev, ks)
+            again = _hip.conv_corr(xd, gd, out_dev, ks)
+            assert torch.equal(got[tile_bytes], again), (shape, ks, tile_bytes)
+            assert (got[tile_bytes].cpu().double() - want).abs().max().item() < tol, (shape, ks, density, tile_bytes)
+        dense_correlation(True)
+        dense = _hip.conv_corr(xd, gd, out_dev, ks)
+        assert (dense.cpu().double() - want).abs().max().item() < tol
+        if density == 0.0:
+            assert not got[0].any()
+
+
+def test_sparse_correlation_c2_shape_and_bf16(hip_device, dense_correlation):
+    """the training shape (64^3 tiles, 9^3 kernel, LiDAR-like density): K4s == K4 within fp32 summation error, for fp32 and
+    bf16 gradient storage; bf16 inputs give the same bits as the same values widened (sums and products are fp32)."""
+    torch.manual_seed(3)
+    shape = (4, 1, 64, 64, 64)
+    x = (torch.rand(shape, device=hip_device) < 0.035)
+    x[:, :, 20:23] |= torch.rand((4, 1, 3, 64, 64), device=hip_device) < 0.25    # "ground" planes
+    g = torch.randn(shape, device=hip_device)
+    o = torch.tanh(torch.randn(shape, device=hip_device)).clamp_min(0.0)
+    dense_correlation(False)
+    sparse = _hip.conv_corr(x, g, o, (9, 9, 9))
+    sparse16 = _hip.conv_corr(x, g.bfloat16(), o.bfloat16(), (9, 9, 9))
+    sparse16w = _hip.conv_corr(x, g.bfloat16().float(), o.bfloat16().float(), (9, 9, 9))
+    dense_correlation(True)
+    dense = _hip.conv_corr(x, g, o, (9, 9, 9))
+    scale = dense.abs().max().item()
+    assert (sparse - dense).abs().max().item() < 2e-5 * scale
+    assert torch.equal(sparse16, sparse16w)
+
+
 @pytest.mark.parametrize("cls,geneo_num,ks", [(sna.SceneNet, {"cy": 2, "cone": 2, "neg": 1}, (9, 7, 7)),
                                               (sna.SCENE_Net, {"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)),
                                               (sna.SceneNet, {"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9))])
