@@ -354,7 +354,7 @@ struct SparseShape {
     int vec;           // list kernel: a thread's 8 input bytes are one aligned load and lie in one row
     unsigned y_magic;  // e / Y == mulhi(e, y_magic) for every e the kernels form (checked on the host)
     unsigned nxt_magic, b_magic;   // likewise job / nxt and (job / nxt) / B for every job index
-    int dbg;           // wrong-result timing switch (SN_CONV_DEBUG builds only: SN_K4S_SKIP): 1 no job does anything
+    int dbg;           // wrong-result timing switch (SN_CONV_DEBUG builds only: SN_K4S_SKIP): 1 no job does anything, 2 no gather
 };
 
 // list index of (b, z', tile xt); the gather reads the lists of z' = z + dz - pz
@@ -467,36 +467,38 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
             n[dz] = (dz < s.kz && zp >= 0 && zp < s.Z) ? counts[i0 + dz * s.nxt] : 0;
         }
     };
-    // chunk c (four entries) of the job's lists, from global memory; chunks past the end read as nothing
+    // chunk c (four entries) of the job's lists, from global memory; chunks past the end read as nothing.  Which list a
+    // chunk belongs to is found without branches (the lengths are wave-uniform, the chunk index is not).
     auto load_chunk = [&](const Job& jb, const int (&n)[KZMAX], int c) -> uint2 {
-        int e = 4 * c, dz = 0;
-        bool found = false;
+        int dz = 0, rel = c, end = 0;
 #pragma unroll
         for (int k = 0; k < KZMAX; ++k) {
-            const int len = n[k] * quad;
-            if (!found) {
-                if (e < len) found = true, dz = k;
-                else e -= len;
-            }
+            end += n[k] * s.groups;              // chunks of lists 0 .. k
+            const bool past = c >= end;
+            dz += past ? 1 : 0;
+            rel = past ? c - end : rel;
         }
         uint2 v = make_uint2(0u, 0u);
-        if (found) {
+        if (c < end) {
             const int idx = list_index(s, jb.b, jb.z - s.pz, jb.xt) + dz * s.nxt;
-            v = *reinterpret_cast<const uint2*>(lists + (size_t)idx * s.capP + e);
+            v = *reinterpret_cast<const uint2*>(lists + (size_t)idx * s.capP + 4 * rel);
         }
         return v;
     };
+    // the delta tile's elements of this thread: loads are unconditional (an element outside the grid reads element 0 and
+    // is zeroed when the tile is written: no divergent control flow around twelve loads)
+    const int nel = s.DR * s.Y;
+    const unsigned e_hi = (unsigned)(s.X * s.Y);
     auto issue_delta = [&](const Job& jb, float (&g)[kSpStage], float (&o)[kSpStage]) {
         const size_t dbase = ((size_t)jb.b * s.Z + jb.z) * plane;
-        const int nel = s.DR * s.Y, e_hi = s.X * s.Y;
 #pragma unroll
         for (int u = 0; u < kSpStage; ++u) {
-            const int e = u * kSpThreads + tid;
-            const int ge = jb.e_lo + e;
             g[u] = 0.f; o[u] = 1.f;
-            if (e < nel && ge >= 0 && ge < e_hi) {
-                g[u] = (float)gout[dbase + ge];
-                if (out) o[u] = (float)out[dbase + ge];
+            if (u * kSpThreads < nel) {   // (uniform)
+                const int ge = jb.e_lo + u * kSpThreads + tid;
+                const unsigned at = (unsigned)ge < e_hi ? (unsigned)ge : 0u;
+                g[u] = (float)gout[dbase + at];
+                if (out) o[u] = (float)out[dbase + at];
             }
         }
     };
@@ -527,7 +529,6 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
         if (work) {
             __syncthreads();   // the previous job's gathers are done with the delta tile and the lists
             // ---- delta tile: rows q0 .. q0 + DR - 1 (zero outside the grid), columns ky - 1 - py + y
-            const int nel = s.DR * s.Y;
 #pragma unroll
             for (int u = 0; u < kSpStage; ++u) {
                 const int e = u * kSpThreads + tid;
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
                     const int rr = (int)__umulhi((unsigned)e, s.y_magic), y = e - rr * s.Y;
                     float d = g[u];
                     if (out) d = (o[u] > 0.f) ? d * (1.f - o[u] * o[u]) : 0.f;
+                    if ((unsigned)(cur.e_lo + e) >= e_hi) d = 0.f;   // a row outside the grid
                     dl[rr * s.P + (s.ky - 1 - s.py) + y] = d;
                 }
             }
@@ -549,16 +551,19 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
         const int next = job + gridDim.x;
         if (next < s.njobs) {
             cur = nxt;
+            int any = 0;
 #pragma unroll
-            for (int dz = 0; dz < KZMAX; ++dz) n[dz] = nn[dz];
-            issue_delta(cur, g, o);
-            chunk = load_chunk(cur, n, tid);
+            for (int dz = 0; dz < KZMAX; ++dz) n[dz] = nn[dz], any |= nn[dz];
+            if (any) {   // (uniform; a job with no set voxel in reach reads nothing)
+                issue_delta(cur, g, o);
+                chunk = load_chunk(cur, n, tid);
+            }
             if (next + (int)gridDim.x < s.njobs) {
                 nxt = decode(next + gridDim.x);
                 list_counts(nxt, nn);
             }
         }
-        if (work) {
+        if (work && !(s.dbg & 2)) {
             // every thread of a wave runs the same rounds (uniform trip counts: scalar loop control); the entries of the
             // next round are requested before this round's four reads
             const uint16_t* q = my_quads;
@@ -568,16 +573,29 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
                 const int nr = rounds[dz];
                 if (nr == 0) continue;
                 float a = acc[dz];
-                uint2 e = *reinterpret_cast<const uint2*>(q);
-                for (int r = 0; r < nr; ++r) {
-                    q += quad;
-                    const uint2 en = *reinterpret_cast<const uint2*>(q);   // (one quad past the last list: slack in `ll`)
+                auto visit4 = [&](const uint2& e) {
                     const float v0 = *reinterpret_cast<const float*>(tap_base + (e.x & 0xffffu));
                     const float v1 = *reinterpret_cast<const float*>(tap_base + (e.x >> 16));
                     const float v2 = *reinterpret_cast<const float*>(tap_base + (e.y & 0xffffu));
                     const float v3 = *reinterpret_cast<const float*>(tap_base + (e.y >> 16));
                     a += v0; a += v1; a += v2; a += v3;
-                    e = en;
+                };
+                // two rounds per trip, the entries of each requested one round ahead into their own registers (hipcc turns
+                // a single rotating pair into "request, wait, copy" at the top of the round: two LDS round trips per round)
+                uint2 ea = *reinterpret_cast<const uint2*>(q);
+                int r = 0;
+                for (; r + 1 < nr; r += 2) {
+                    const uint2 eb = *reinterpret_cast<const uint2*>(q + quad);
+                    __builtin_amdgcn_sched_barrier(0);
+                    visit4(ea);
+                    q += 2 * quad;
+                    ea = *reinterpret_cast<const uint2*>(q);   // (one quad past the last list: slack in `ll`)
+                    __builtin_amdgcn_sched_barrier(0);
+                    visit4(eb);
+                }
+                if (r < nr) {
+                    visit4(ea);
+                    q += quad;
                 }
                 acc[dz] = a;
             }
