@@ -17,6 +17,7 @@ cp $S/train_bench.txt $P/${TAG}_train_bench.txt
 cp $S/train_bench_bf16.txt $P/${TAG}_train_bench_bf16.txt
 cp $S/step_host.txt $P/${TAG}_step_host.txt
 cp $S/k1_time.txt $P/${TAG}_k1_time.txt
+cp $S/corr_time.txt $P/${TAG}_corr_time.txt
 cp $S/zwalk_repeat.txt $P/${TAG}_zwalk_repeat.txt
 tail -3 $S/pytest_gpu.txt > $P/${TAG}_pytest_gpu_tail.txt
 python3 tools/traffic_json.py $S/pmc_traffic.csv $P/traffic.json ${TAG}_pmc_traffic.csv --keep-missing

@@ -23,6 +23,7 @@ python tools/c4_bench.py --batch 32 --voxel-size 0.9 0.9 0.9 >> $O/c4.txt 2>&1 |
 python tools/conv_ab.py --rounds 3 > $O/conv_ab.txt 2>&1 || true
 python tools/step_host_profile.py > $O/step_host.txt 2>&1 || true
 python tools/k1_time.py > $O/k1_time.txt 2>&1 || true
+python tools/corr_time.py > $O/corr_time.txt 2>&1 || true
 # the z-walk's hand-over protocol under repetition (a race would show as a wrong bit or a spin timeout, intermittently)
 for i in 1 2 3 4 5; do python -m pytest tests/test_gpu_conv_zwalk.py -q -p no:cacheprovider 2>&1 | tail -1; done > $O/zwalk_repeat.txt
 # PMC passes
