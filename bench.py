@@ -201,16 +201,17 @@ def main():
     conv_ev, vox_ev = [], []
 
     def step(timed):
-        # K2 (GENEO bank + the int8 contraction's per-bank preparation, ONE launch) is forked onto a side stream: it reads
-        # only the model's scalars, so it runs beside K1 and is joined in front of K3' (scene-net_amd/pipeline.py)
-        bank, lam, prep, join = pipe.bank_beside(dev)
+        # K2 (GENEO bank + the int8 contraction's per-bank preparation) RIDES in K1's first launch: 16 extra workgroups of the
+        # bounding-box kernel (sn_voxel_occupancy_fused_bank; scene-net_amd/pipeline.py does the same) -- it reads only the
+        # model's scalars.  [measured] forked onto a side stream it left 10.8 of its 12.4 serial us on the critical path.
+        _, _, bank, prep = rider = model.bank_rider(dev)
+        lam = model.effective_lambdas(dev)
         if timed:
             a, b, c = ev(), ev(), ev()
             a.record()
-        grids = pipe.voxelize(batch)
+        grids = pipe.voxelize(batch, bank_rider=rider)
         if timed:
             b.record()
-        join()
         if timed:
             c0 = ev()
             c0.record()
@@ -425,7 +426,7 @@ def main():
         g_ms = (time.perf_counter() - ts) / args.steps * 1e3
         graph_info = {"ms_per_step": g_ms, "tiles_per_s_per_gpu": B / (g_ms * 1e-3),
                       "identical_output": bool(torch.equal(out_graph, out)),
-                      "note": "whole step (4 voxel launches; bank + preparation on a parallel branch; conv) replayed "
+                      "note": "whole step (4 voxel launches, the bank + preparation riding in the first; conv) replayed "
                               "from one hipGraph"}
         del graph
         if fused_info is not None:   # the 0.12 ms fused step is at the edge of being host bound when launched eagerly

@@ -55,6 +55,8 @@ SYMBOLS = {
     "sn_voxel_occupancy": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "sn_voxel_occupancy_fused": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
                                          _P]),
+    "sn_voxel_occupancy_fused_bank": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P,
+                                              _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_voxel_occupancy_sized": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P,
                                          _P, _P, _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -576,9 +578,11 @@ def voxel_occupancy(pts, labels, offsets, desc, n_xyz, keep_labels: Sequence[flo
 @_on_tensor_device
 def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, keep_labels: Sequence[float] = (),
                           want_gt_occ: bool = False, out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True,
-                          want_bbox: bool = False):
+                          want_bbox: bool = False, bank_rider=None):
     """sn_voxel_occupancy_fused: bbox + descriptor + LDS-bitmap occupancy in four launches.  Returns
-    (occ, gt_occ | None, flags, dropped, desc, bbox | None)."""
+    (occ, gt_occ | None, flags, dropped, desc, bbox | None).  bank_rider = (params [G, SN_NPARAM] f32, kinds [G] i32,
+    bank [G,9,9,9] f32 out, prep uint8 out): K2 and the int8 contraction's preparation ride in the first launch
+    (sn_voxel_occupancy_fused_bank) -- the two output buffers hold what sn_geneo_bank_prep would have written."""
     B = offsets.numel() - 1
     nx, ny, nz = (int(v) for v in n_xyz)
     V = nx * ny * nz
@@ -597,14 +601,23 @@ def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, kee
         counts = torch.empty((B, V), dtype=torch.int32, device=dev)
         towers = torch.empty((B, V), dtype=torch.int32, device=dev) if want_gt_occ else None
     keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
-    rc = load().sn_voxel_occupancy_fused(_ptr(pts, torch.float64, "pts"),
-                                         _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
-                                         _ptr(offsets, torch.int64, "offsets"), B, nx, ny, nz, int(regular),
-                                         ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
-                                         _ptr(partial), _ptr(bbox), _ptr(desc), _ptr(bits), _ptr(occ), _ptr(gt_occ),
-                                         _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped), _ptr(counts), _ptr(towers),
-                                         _stream())
-    _check(rc, "sn_voxel_occupancy_fused")
+    common = (_ptr(pts, torch.float64, "pts"), _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
+              _ptr(offsets, torch.int64, "offsets"), B, nx, ny, nz, int(regular), ctypes.cast(keep, c_void_p),
+              len(keep_labels) if want_gt_occ else 0, _ptr(partial), _ptr(bbox), _ptr(desc), _ptr(bits), _ptr(occ),
+              _ptr(gt_occ), _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped), _ptr(counts), _ptr(towers))
+    if bank_rider is None:
+        rc = load().sn_voxel_occupancy_fused(*common, _stream())
+        _check(rc, "sn_voxel_occupancy_fused")
+    else:
+        params, kinds, bank, prep = bank_rider
+        G = params.shape[0]
+        if tuple(bank.shape) != (G, 9, 9, 9) or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
+            raise HipLibraryError("bank_rider: bank must be [G,9,9,9] f32 and prep SN_CONV_PREP_BYTES x ceil(G / 16) bytes")
+        rc = load().sn_voxel_occupancy_fused_bank(*common, _ptr(params, torch.float32, "params"),
+                                                  _ptr(kinds, torch.int32, "kinds"), G, 9, 9, 9,
+                                                  _ptr(bank, torch.float32, "bank"), None, _ptr(prep, torch.uint8, "prep"),
+                                                  _stream())
+        _check(rc, "sn_voxel_occupancy_fused_bank")
     return occ, gt_occ, flags, dropped, desc, bbox
 
 

@@ -29,7 +29,16 @@
 
 namespace {
 
+// K2's device code rides in K1's first launch (bbox_partial_bank_kernel).  This file is compiled with -ffp-contract=off
+// (numpy's rounding sequence, Makefile); the bank builder and the preparation are compiled with hipcc's default
+// contraction in bank.hip, and must give the same bits here: the pragma restores that default for their code only.
+#pragma clang fp contract(fast)
+#include "conv_prep.h"
+#include "bank_body.inc"
+#pragma clang fp contract(off)
+
 constexpr int kThreads = 256;
+static_assert(kThreads == kBankThreads, "the rider workgroups have the bank builder's thread count");
 constexpr int kMaxKeep = 16;
 #ifndef SN_OCC_THREADS
 #define SN_OCC_THREADS 512
@@ -179,11 +188,9 @@ __global__ void bbox_decode_kernel(unsigned long long* enc, const int64_t* __res
 
 // Fused form for the batch pipeline: per-workgroup partial boxes (no atomics, nothing to initialise) ...
 template <bool kAligned>
-__global__ __launch_bounds__(kThreads) void bbox_partial_kernel(const double* __restrict__ pts,
-                                                                const int64_t* __restrict__ offsets,
-                                                                double* __restrict__ partial) {
+__device__ __forceinline__ void bbox_partial_body(const double* __restrict__ pts, const int64_t* __restrict__ offsets,
+                                                  double* __restrict__ partial, const int b) {
     __shared__ double red[kThreads / 64][6];
-    const int b = blockIdx.y;
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
     for_each_point<kAligned>(pts, offsets[b], offsets[b + 1], (long)blockIdx.x * kThreads + threadIdx.x,
                              (long)gridDim.x * kThreads, [&](double x, double y, double z, long) {
@@ -213,6 +220,44 @@ __global__ __launch_bounds__(kThreads) void bbox_partial_kernel(const double* __
         for (int w = 1; w < kThreads / 64; ++w) v = (c < 3) ? fmin(v, red[w][c]) : fmax(v, red[w][c]);
         partial[((size_t)b * gridDim.x + blockIdx.x) * 6 + c] = v;
     }
+}
+
+template <bool kAligned>
+__global__ __launch_bounds__(kThreads) void bbox_partial_kernel(const double* __restrict__ pts,
+                                                                const int64_t* __restrict__ offsets,
+                                                                double* __restrict__ partial) {
+    bbox_partial_body<kAligned>(pts, offsets, partial, blockIdx.y);
+}
+
+// The same launch with K2 as RIDERS (sn_voxel_occupancy_fused_bank): the FIRST grid rows (blockIdx.y < rider_rows: dispatched
+// first -- a rider runs ~6 us, and started last it would be the launch's tail) are not tiles -- workgroup y gridDim.x + x
+// builds GENEO kernel g of the bank and its share of the int8 contraction's preparation blob
+// (geneo_bank_body<true>, exactly what sn_geneo_bank_prep launches), beside the HBM-bound box pass.  [measured, round 3,
+// tools/debug/fork_cost.py] K2 on a side stream (one event record + one wait on the main stream) left 10.8 of its 12.4
+// serial microseconds on the step's critical path: 152.2 us forked, 153.8 serial, 141.4 with K2 left out.
+struct BankRider {
+    const float* params;
+    const int32_t* kinds;
+    float* bank;
+    int32_t* status;
+    uint8_t* prep;
+    int G, nblocks;
+};
+
+template <bool kAligned>
+__global__ __launch_bounds__(kThreads) void bbox_partial_bank_kernel(const double* __restrict__ pts,
+                                                                     const int64_t* __restrict__ offsets,
+                                                                     double* __restrict__ partial, int rider_rows,
+                                                                     BankRider r) {
+    if ((int)blockIdx.y < rider_rows) {
+        __shared__ float bank_lds[729 + 9 + 1 + 8 + 1];
+        const int g = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        if (g < r.nblocks)
+            geneo_bank_body<true>(bank_lds, g, threadIdx.x, r.params, r.kinds, 9, 9, 9, r.bank, r.status, r.G, nullptr,
+                                  nullptr, 0, nullptr, r.prep);
+        return;
+    }
+    bbox_partial_body<kAligned>(pts, offsets, partial, (int)blockIdx.y - rider_rows);
 }
 
 // ---------------------------------------------------------------- grid descriptor
@@ -1175,6 +1220,42 @@ extern "C" int sn_voxel_occupancy_fused(const double* pts, const double* labels,
     else
         hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
     if (int rc = sn::check_launch("sn_voxel_occupancy_fused(bbox)")) return rc;
+    return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
+                          out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
+                          bbox, stream);
+}
+
+extern "C" int sn_voxel_occupancy_fused_bank(const double* pts, const double* labels, const int64_t* offsets, int B, int nx,
+                                             int ny, int nz, int regular, const double* keep_labels_host, int n_keep,
+                                             double* partial_ws, double* bbox, double* desc, uint32_t* bits_ws, void* occ,
+                                             void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                                             int32_t* counts_ws, int32_t* towers_ws, const float* params,
+                                             const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                                             int32_t* status, void* prep, sn_stream_t stream) {
+    if (!pts || !offsets || !partial_ws || !desc)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: null pointer");
+    if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: non-positive extent (B=%d n=%d,%d,%d)", B, nx,
+                        ny, nz);
+    if (!params || !kinds || !bank || !prep)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: null bank argument");
+    if (G <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: bad G");
+    if (kz != 9 || kx != 9 || ky != 9)
+        return sn::fail(SN_ERR_UNSUPPORTED,
+                        "sn_voxel_occupancy_fused_bank: the prepared contraction serves 9 x 9 x 9 kernels (got %d,%d,%d)", kz, kx,
+                        ky);
+    if (reinterpret_cast<uintptr_t>(prep) & 15)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: prep must be 16-byte aligned");
+    hipStream_t s = sn::as_stream(stream);
+    BankRider r{params, kinds, bank, status, static_cast<uint8_t*>(prep), G, 16 * ((G + 15) / 16)};
+    const int extra_rows = (r.nblocks + SN_BBOX_PARTS - 1) / SN_BBOX_PARTS;
+    dim3 grid(SN_BBOX_PARTS, B + extra_rows);
+    if (aligned16(pts))
+        hipLaunchKernelGGL(bbox_partial_bank_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws, extra_rows, r);
+    else
+        hipLaunchKernelGGL(bbox_partial_bank_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws, extra_rows,
+                           r);
+    if (int rc = sn::check_launch("sn_voxel_occupancy_fused_bank(bbox + bank)")) return rc;
     return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
                           out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
                           bbox, stream);

@@ -71,10 +71,17 @@ class ScenePipeline:
         self.overlap_bank = bool(overlap_bank)
         self._side = None
 
-    def voxelize(self, batch: PointBatch, want_gt: bool = False) -> VoxelGrids:
+    def voxelize(self, batch: PointBatch, want_gt: bool = False, bank_rider=None) -> VoxelGrids:
         # binary occupancy as torch.bool: 1 byte/voxel between K1 and K3, and K3 runs on the int8 matrix cores
         return voxelize_batch(batch, self.voxelgrid_dims, self.keep_labels, want_occ=True, want_gt_occ=want_gt,
-                              occ_dtype=torch.bool, voxel_dims=self.voxel_dims)
+                              occ_dtype=torch.bool, voxel_dims=self.voxel_dims, bank_rider=bank_rider)
+
+    def rides(self) -> bool:
+        """K2 can ride in K1's first launch: a 9^3 bank (the prepared contraction) and the n-mode occupancy path"""
+        from . import _hip as h
+        return (self.overlap_bank and self.voxel_dims is None and self.model.kernel_size_of_bank() == (9, 9, 9)
+                and not self.model.fused_forward
+                and h.occupancy_supported(tuple(int(v) for v in self.voxelgrid_dims), 1))
 
     def _finish(self, out, grids, batch, want_gt):
         if self.per_point:
@@ -112,6 +119,16 @@ class ScenePipeline:
         # inference: the module's own no-grad forward (scene_net.py), with K2 forked beside K1
         with torch.no_grad():
             dev = batch.pts.device
+            if self.rides() and not want_gt:
+                # K2 as riders of K1's first launch ([measured] forked onto a side stream it still cost the main stream
+                # 10.8 of its 12.4 serial microseconds: an event record and a wait)
+                _, _, bank, prep = rider = model.bank_rider(dev)
+                lam = model.effective_lambdas(dev)
+                grids = self.voxelize(batch, want_gt, bank_rider=rider)
+                if not grids.rider_done:   # (the voxelisation took a path without the rider: K2 as its own launch)
+                    bank, prep = model.compute_bank_prepared(dev)
+                out = model.contract_prepared(grids.occ, bank, lam, prep)[1]
+                return self._finish(out, grids, batch, want_gt)
             bank, lam, prep, join = self.bank_beside(dev)
             grids = self.voxelize(batch, want_gt)
             join()

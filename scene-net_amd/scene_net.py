@@ -269,6 +269,23 @@ class SceneNet(nn.Module):
         bank, _, prep = _hip.geneo_bank_prep(params, kinds, bank=bufs[0], prep=bufs[1])
         return bank, prep
 
+    def bank_rider(self, device=None):
+        """(params, kinds, bank, prep): what compute_bank_prepared would launch, as arguments for K1's first launch
+        (voxelize_batch(bank_rider=...) -> sn_voxel_occupancy_fused_bank): the bank and the preparation blob are then
+        written by extra workgroups of the bounding-box kernel -- no launch, no stream fork, no event for K2.  The two
+        buffers are the model's persistent ones (compute_bank_prepared's)."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.kernel_size_of_bank() != (9, 9, 9):
+            raise _hip.HipLibraryError("bank_rider serves 9 x 9 x 9 kernels")
+        params, kinds = self.packed_params(device)
+        G = params.shape[0]
+        bufs = self.__dict__.get("_prepared_bufs")
+        if bufs is None or bufs[0].device != device or bufs[0].shape[0] != G:
+            bufs = (torch.empty((G, 9, 9, 9), dtype=torch.float32, device=device),
+                    torch.zeros(_hip.SN_CONV_PREP_BYTES * ((G + 15) // 16), dtype=torch.uint8, device=device))
+            self.__dict__["_prepared_bufs"] = bufs
+        return params, kinds, bufs[0], bufs[1]
+
     def contract_prepared(self, x: torch.Tensor, bank: torch.Tensor, lam: torch.Tensor, prep: torch.Tensor,
                           want_act: bool = False, out_dtype: Optional[torch.dtype] = None):
         """sn_conv_bank_prepared on (bank, lam, prep) of THIS model's current parameters -> (act | None, out).  The walk's

@@ -75,6 +75,7 @@ class VoxelGrids:
     flags: Optional[torch.Tensor] = None  # [B] i32, occupancy path: tiles redone by the counting kernels
     dims: Optional[torch.Tensor] = None   # [B,3] i32 (n_x, n_y, n_z) per tile -- voxel-size mode: grids are padded to the maximum
     status: Optional[torch.Tensor] = None  # [B] i32, voxel-size mode: 1 = the tile needs more voxels than the maximum
+    rider_done: bool = False               # the bank rider handed to voxelize_batch ran with the first launch
 
 
 def _labels_list(tower_label) -> List[float]:
@@ -86,7 +87,7 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
                    want_gt: bool = False, want_occ: bool = True, want_gt_occ: bool = False,
                    bounds: Optional[torch.Tensor] = None, want_counts: bool = False,
                    occ_dtype: torch.dtype = torch.float32,
-                   voxel_dims: Optional[Sequence[float]] = None) -> VoxelGrids:
+                   voxel_dims: Optional[Sequence[float]] = None, bank_rider=None) -> VoxelGrids:
     """voxelize_ply for a whole batch.  `voxelgrid_dims` is (x, y, z) like the reference
     (pcd_processing.py:362-363); grids come back [.., nz, nx, ny] (voxelization.py:193).
 
@@ -131,8 +132,11 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
     if occupancy_only and bounds is None:   # the hot path: bbox, descriptor, bitmap, expansion in four launches
         occ, gt_occ, flags, dropped, desc, _ = _hip.voxel_occupancy_fused(
             batch.pts, batch.labels if want_t else None, batch.offsets, (nx, ny, nz), True,
-            _labels_list(keep_labels) if want_t else (), want_gt_occ=want_gt_occ, out_dtype=occ_dtype)
-        return VoxelGrids(None, None, None, None, occ, gt_occ, desc, dropped, flags)
+            _labels_list(keep_labels) if want_t else (), want_gt_occ=want_gt_occ, out_dtype=occ_dtype,
+            bank_rider=bank_rider)
+        grids = VoxelGrids(None, None, None, None, occ, gt_occ, desc, dropped, flags)
+        grids.rider_done = bank_rider is not None
+        return grids
     if bounds is None:
         desc, _ = _hip.voxel_prepare(batch.pts, batch.offsets, (nx, ny, nz), regular=True)
     else:

@@ -186,6 +186,52 @@ def test_bank_builder_prepares_what_the_standalone_preparation_does(hip_device, 
         assert sym.tolist() == [1] * 16          # every GENEO family is symmetric in x and y, bit for bit; pads too
 
 
+@pytest.mark.parametrize("geneo_num", [{"cy": 6, "cone": 5, "neg": 5}, {"cy": 2, "cone": 1, "neg": 1},
+                                       {"cy": 7, "cone": 7, "neg": 6}])
+def test_bank_riding_in_the_voxelisation_launch(hip_device, geneo_num):
+    """sn_voxel_occupancy_fused_bank: K2 + the preparation as extra workgroups of K1's first launch == sn_geneo_bank_prep
+    (bank and every field of the blob a kernel reads, bit for bit: the bank code is compiled into voxel.hip under the
+    contraction setting of bank.hip) next to == sn_voxel_occupancy_fused (occupancy, flags, descriptor); G = 16, 4, 20
+    (two groups: the rider rows outnumber one row of the grid); unaligned points too."""
+    from scene_net_amd.synthetic import synthetic_tile
+    model = _bench_model(hip_device, geneo_num)
+    bank_p, prep_p = model.compute_bank_prepared(hip_device)
+    bank_p, prep_p = bank_p.clone(), prep_p.clone()
+    tiles = [synthetic_tile(i, 20_000 + 1000 * i)[0] for i in range(3)]
+    batch = sna.PointBatch.from_tiles(tiles, device=hip_device)
+    plain = sna.voxelize_batch(batch, (64, 64, 64), occ_dtype=torch.bool)
+    params, kinds, bank, prep = model.bank_rider(hip_device)
+    bank.fill_(float("nan")); prep.zero_()
+    rode = sna.voxelize_batch(batch, (64, 64, 64), occ_dtype=torch.bool, bank_rider=(params, kinds, bank, prep))
+    assert rode.rider_done and not plain.rider_done
+    assert torch.equal(rode.occ, plain.occ) and torch.equal(rode.flags, plain.flags) and torch.equal(rode.desc, plain.desc)
+    assert torch.equal(bank, bank_p)
+    G = bank.shape[0]
+    for grp in range((G + 15) // 16):
+        a = prep[grp * _hip.SN_CONV_PREP_BYTES:(grp + 1) * _hip.SN_CONV_PREP_BYTES].cpu().numpy()
+        b = prep_p[grp * _hip.SN_CONV_PREP_BYTES:(grp + 1) * _hip.SN_CONV_PREP_BYTES].cpu().numpy()
+        for name, lo, hi in [("digit table", 0, 12288), ("scales", 12288, 12352), ("bounds", 12352, 12480),
+                             ("symmetry", 12480, 12544), ("fit", 12544, 12608), ("magic", 12608, 12612)]:
+            assert np.array_equal(a[lo:hi], b[lo:hi]), (grp, name)
+    # an unaligned point buffer (the other instantiation of the launch)
+    pts_u = torch.empty(batch.pts.numel() + 1, dtype=torch.float64, device=hip_device)[1:].view_as(batch.pts)
+    pts_u.copy_(batch.pts)
+    bank.fill_(float("nan"))
+    occ_u = _hip.voxel_occupancy_fused(pts_u, None, batch.offsets, (64, 64, 64), out_dtype=torch.bool,
+                                       bank_rider=(params, kinds, bank, prep))[0]
+    assert torch.equal(occ_u, plain.occ) and torch.equal(bank, bank_p)
+    # a pipeline pass with the rider == the serial pass, eagerly and replayed from a hipGraph
+    model.fused_forward = False
+    with torch.no_grad():
+        serial = sna.ScenePipeline(model, (64, 64, 64), overlap_bank=False)(batch)
+        pipe = sna.ScenePipeline(model, (64, 64, 64), overlap_bank=True)
+        assert pipe.rides()
+        assert torch.equal(pipe(batch), serial)
+        cap = pipe.capture(batch)
+        assert torch.equal(cap.replay(), serial)
+    model.fused_forward = True
+
+
 def test_pipeline_with_the_bank_forked_beside_the_voxelisation(hip_device):
     """ScenePipeline(overlap_bank=True): K2 on a side stream next to K1, joined before K3 -- the same bits as the serial
     pass, for the 16-kernel contraction and for the forward through linearity, eagerly and replayed from a hipGraph."""
