@@ -339,6 +339,15 @@ int sn_voxel_occupancy_sized(const double* pts, const double* labels, const int6
                              double* desc, int32_t* dims, int32_t* status, uint32_t* bits_ws, void* occ,
                              void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
                              int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream);
+/* sn_voxel_occupancy_sized with the same riders as sn_voxel_occupancy_fused_bank (C4's chain: voxel-size mode -> conv). */
+int sn_voxel_occupancy_sized_bank(const double* pts, const double* labels, const int64_t* offsets, int B,
+                                  const double* size_xyz_host, int nx, int ny, int nz, const double* keep_labels_host,
+                                  int n_keep, double* partial_ws, double* bbox, double* desc, int32_t* dims, int32_t* status,
+                                  uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype, int32_t* flags,
+                                  int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws, const float* params,
+                                  const int32_t* kinds, int G, int kz, int kx, int ky, float* bank, int32_t* bank_status,
+                                  void* prep, sn_stream_t stream);
+
 
 /* Grid -> points: out[c, i] = grid[b(i), c, vz, vx, vy] for every point i of the batch, binned exactly as the
  * scatter binned it (same desc); points outside the edge table get `fill`.  grid [B,channels,nz,nx,ny] and

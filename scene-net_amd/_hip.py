@@ -59,6 +59,8 @@ SYMBOLS = {
                                               _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_voxel_occupancy_sized": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P,
                                          _P, _P, _P]),
+    "sn_voxel_occupancy_sized_bank": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
+                                              _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
     "sn_grid_to_points": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -623,7 +625,8 @@ def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, kee
 
 @_on_tensor_device
 def voxel_occupancy_sized(pts, labels, offsets, size_xyz: Sequence[float], n_xyz_max, keep_labels: Sequence[float] = (),
-                          want_gt_occ: bool = False, out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True):
+                          want_gt_occ: bool = False, out_dtype: torch.dtype = torch.uint8, exact_fallback: bool = True,
+                          bank_rider=None):
     """sn_voxel_occupancy_sized: voxel-size mode on the LDS-bitmap kernels.  Returns
     (occ, gt_occ | None, flags, dropped, desc, dims [B,3], status [B], bbox [B,6])."""
     B = offsets.numel() - 1
@@ -647,14 +650,23 @@ def voxel_occupancy_sized(pts, labels, offsets, size_xyz: Sequence[float], n_xyz
         towers = torch.empty((B, V), dtype=torch.int32, device=dev) if want_gt_occ else None
     keep = (ctypes.c_double * max(1, len(keep_labels)))(*[float(k) for k in keep_labels])
     size = (ctypes.c_double * 3)(*[float(v) for v in size_xyz])
-    rc = load().sn_voxel_occupancy_sized(_ptr(pts, torch.float64, "pts"),
-                                         _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
-                                         _ptr(offsets, torch.int64, "offsets"), B, ctypes.cast(size, c_void_p), nx, ny, nz,
-                                         ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0,
-                                         _ptr(partial), _ptr(bbox), _ptr(desc), _ptr(dims), _ptr(status), _ptr(bits),
-                                         _ptr(occ), _ptr(gt_occ), _DT_OUT[out_dtype], _ptr(flags), _ptr(dropped),
-                                         _ptr(counts), _ptr(towers), _stream())
-    _check(rc, "sn_voxel_occupancy_sized")
+    common = (_ptr(pts, torch.float64, "pts"), _ptr(labels, torch.float64, "labels") if want_gt_occ else None,
+              _ptr(offsets, torch.int64, "offsets"), B, ctypes.cast(size, c_void_p), nx, ny, nz,
+              ctypes.cast(keep, c_void_p), len(keep_labels) if want_gt_occ else 0, _ptr(partial), _ptr(bbox), _ptr(desc),
+              _ptr(dims), _ptr(status), _ptr(bits), _ptr(occ), _ptr(gt_occ), _DT_OUT[out_dtype], _ptr(flags),
+              _ptr(dropped), _ptr(counts), _ptr(towers))
+    if bank_rider is None:
+        _check(load().sn_voxel_occupancy_sized(*common, _stream()), "sn_voxel_occupancy_sized")
+    else:   # (as voxel_occupancy_fused: K2 + the preparation ride in the first launch)
+        params, kinds, bank, prep = bank_rider
+        G = params.shape[0]
+        if tuple(bank.shape) != (G, 9, 9, 9) or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
+            raise HipLibraryError("bank_rider: bank must be [G,9,9,9] f32 and prep SN_CONV_PREP_BYTES x ceil(G / 16) bytes")
+        rc = load().sn_voxel_occupancy_sized_bank(*common, _ptr(params, torch.float32, "params"),
+                                                  _ptr(kinds, torch.int32, "kinds"), G, 9, 9, 9,
+                                                  _ptr(bank, torch.float32, "bank"), None, _ptr(prep, torch.uint8, "prep"),
+                                                  _stream())
+        _check(rc, "sn_voxel_occupancy_sized_bank")
     return occ, gt_occ, flags, dropped, desc, dims, status, bbox
 
 

@@ -1225,6 +1225,30 @@ extern "C" int sn_voxel_occupancy_fused(const double* pts, const double* labels,
                           bbox, stream);
 }
 
+// the bounding-box launch of the fused entry points, with K2's workgroups as riders when a bank is handed in
+static int check_rider(const char* who, const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                       void* prep) {
+    if (!params || !kinds || !bank || !prep) return sn::fail(SN_ERR_INVALID_ARG, "%s: null bank argument", who);
+    if (G <= 0) return sn::fail(SN_ERR_INVALID_ARG, "%s: bad G", who);
+    if (kz != 9 || kx != 9 || ky != 9)
+        return sn::fail(SN_ERR_UNSUPPORTED, "%s: the prepared contraction serves 9 x 9 x 9 kernels (got %d,%d,%d)", who, kz, kx,
+                        ky);
+    if (reinterpret_cast<uintptr_t>(prep) & 15) return sn::fail(SN_ERR_INVALID_ARG, "%s: prep must be 16-byte aligned", who);
+    return SN_OK;
+}
+
+static void launch_bbox_with_riders(const double* pts, const int64_t* offsets, double* partial_ws, int B, const float* params,
+                                    const int32_t* kinds, int G, float* bank, int32_t* status, void* prep, hipStream_t s) {
+    BankRider r{params, kinds, bank, status, static_cast<uint8_t*>(prep), G, 16 * ((G + 15) / 16)};
+    const int extra_rows = (r.nblocks + SN_BBOX_PARTS - 1) / SN_BBOX_PARTS;
+    dim3 grid(SN_BBOX_PARTS, B + extra_rows);
+    if (aligned16(pts))
+        hipLaunchKernelGGL(bbox_partial_bank_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws, extra_rows, r);
+    else
+        hipLaunchKernelGGL(bbox_partial_bank_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws, extra_rows,
+                           r);
+}
+
 extern "C" int sn_voxel_occupancy_fused_bank(const double* pts, const double* labels, const int64_t* offsets, int B, int nx,
                                              int ny, int nz, int regular, const double* keep_labels_host, int n_keep,
                                              double* partial_ws, double* bbox, double* desc, uint32_t* bits_ws, void* occ,
@@ -1237,52 +1261,40 @@ extern "C" int sn_voxel_occupancy_fused_bank(const double* pts, const double* la
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: non-positive extent (B=%d n=%d,%d,%d)", B, nx,
                         ny, nz);
-    if (!params || !kinds || !bank || !prep)
-        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: null bank argument");
-    if (G <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: bad G");
-    if (kz != 9 || kx != 9 || ky != 9)
-        return sn::fail(SN_ERR_UNSUPPORTED,
-                        "sn_voxel_occupancy_fused_bank: the prepared contraction serves 9 x 9 x 9 kernels (got %d,%d,%d)", kz, kx,
-                        ky);
-    if (reinterpret_cast<uintptr_t>(prep) & 15)
-        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: prep must be 16-byte aligned");
-    hipStream_t s = sn::as_stream(stream);
-    BankRider r{params, kinds, bank, status, static_cast<uint8_t*>(prep), G, 16 * ((G + 15) / 16)};
-    const int extra_rows = (r.nblocks + SN_BBOX_PARTS - 1) / SN_BBOX_PARTS;
-    dim3 grid(SN_BBOX_PARTS, B + extra_rows);
-    if (aligned16(pts))
-        hipLaunchKernelGGL(bbox_partial_bank_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws, extra_rows, r);
-    else
-        hipLaunchKernelGGL(bbox_partial_bank_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws, extra_rows,
-                           r);
+    if (int rc = check_rider("sn_voxel_occupancy_fused_bank", params, kinds, G, kz, kx, ky, bank, prep)) return rc;
+    launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, status, prep, sn::as_stream(stream));
     if (int rc = sn::check_launch("sn_voxel_occupancy_fused_bank(bbox + bank)")) return rc;
     return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
                           out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
                           bbox, stream);
 }
 
-extern "C" int sn_voxel_occupancy_sized(const double* pts, const double* labels, const int64_t* offsets, int B,
-                                        const double* size_xyz_host, int nx, int ny, int nz,
-                                        const double* keep_labels_host, int n_keep, double* partial_ws, double* bbox,
-                                        double* desc, int32_t* dims, int32_t* status, uint32_t* bits_ws, void* occ,
-                                        void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
-                                        int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream) {
+static int occupancy_sized_impl(const char* who, const double* pts, const double* labels, const int64_t* offsets, int B,
+                                const double* size_xyz_host, int nx, int ny, int nz, const double* keep_labels_host,
+                                int n_keep, double* partial_ws, double* bbox, double* desc, int32_t* dims, int32_t* status,
+                                uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                                int32_t* counts_ws, int32_t* towers_ws, bool rider, const float* params,
+                                const int32_t* kinds, int G, float* bank, int32_t* bank_status, void* prep,
+                                sn_stream_t stream) {
     if (!pts || !offsets || !partial_ws || !desc || !dims || !size_xyz_host)
-        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_sized: null pointer");
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: null pointer", who);
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
-        return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_sized: non-positive extent (B=%d n=%d,%d,%d)", B, nx, ny,
-                        nz);
+        return sn::fail(SN_ERR_INVALID_ARG, "%s: non-positive extent (B=%d n=%d,%d,%d)", who, B, nx, ny, nz);
     Vec3s sz;
     for (int c = 0; c < 3; ++c) {
         sz.v[c] = size_xyz_host[c];
-        if (!(sz.v[c] > 0.0)) return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_sized: voxel size must be > 0");
+        if (!(sz.v[c] > 0.0)) return sn::fail(SN_ERR_INVALID_ARG, "%s: voxel size must be > 0", who);
     }
     hipStream_t s = sn::as_stream(stream);
-    dim3 grid(SN_BBOX_PARTS, B);
-    if (aligned16(pts))
-        hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
-    else
-        hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    if (rider) {
+        launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, bank_status, prep, s);
+    } else {
+        dim3 grid(SN_BBOX_PARTS, B);
+        if (aligned16(pts))
+            hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+        else
+            hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+    }
     // per-tile grid extents and padded edge tables from the partial boxes, on the device (no host round trip)
     hipLaunchKernelGGL(desc_sized_kernel, dim3(B), dim3(128), 0, s, partial_ws, SN_BBOX_PARTS, sz, nx, ny, nz, desc, dims,
                        status, bbox);
@@ -1291,6 +1303,32 @@ extern "C" int sn_voxel_occupancy_sized(const double* pts, const double* labels,
     // edges there are +inf); the column rule of ToFullDense(normalize_xyz(.)) looks at each tile's own part only
     return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
                           out_dtype, flags, dropped, counts_ws, towers_ws, nullptr, 0, 0, nullptr, stream, dims);
+}
+
+extern "C" int sn_voxel_occupancy_sized(const double* pts, const double* labels, const int64_t* offsets, int B,
+                                        const double* size_xyz_host, int nx, int ny, int nz,
+                                        const double* keep_labels_host, int n_keep, double* partial_ws, double* bbox,
+                                        double* desc, int32_t* dims, int32_t* status, uint32_t* bits_ws, void* occ,
+                                        void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                                        int32_t* counts_ws, int32_t* towers_ws, sn_stream_t stream) {
+    return occupancy_sized_impl("sn_voxel_occupancy_sized", pts, labels, offsets, B, size_xyz_host, nx, ny, nz,
+                                keep_labels_host, n_keep, partial_ws, bbox, desc, dims, status, bits_ws, occ, gt_occ, out_dtype,
+                                flags, dropped, counts_ws, towers_ws, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                                stream);
+}
+
+extern "C" int sn_voxel_occupancy_sized_bank(const double* pts, const double* labels, const int64_t* offsets, int B,
+                                             const double* size_xyz_host, int nx, int ny, int nz,
+                                             const double* keep_labels_host, int n_keep, double* partial_ws, double* bbox,
+                                             double* desc, int32_t* dims, int32_t* status, uint32_t* bits_ws, void* occ,
+                                             void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
+                                             int32_t* counts_ws, int32_t* towers_ws, const float* params,
+                                             const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
+                                             int32_t* bank_status, void* prep, sn_stream_t stream) {
+    if (int rc = check_rider("sn_voxel_occupancy_sized_bank", params, kinds, G, kz, kx, ky, bank, prep)) return rc;
+    return occupancy_sized_impl("sn_voxel_occupancy_sized_bank", pts, labels, offsets, B, size_xyz_host, nx, ny, nz,
+                                keep_labels_host, n_keep, partial_ws, bbox, desc, dims, status, bits_ws, occ, gt_occ, out_dtype,
+                                flags, dropped, counts_ws, towers_ws, true, params, kinds, G, bank, bank_status, prep, stream);
 }
 
 extern "C" int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets,

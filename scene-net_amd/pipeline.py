@@ -76,12 +76,11 @@ class ScenePipeline:
         return voxelize_batch(batch, self.voxelgrid_dims, self.keep_labels, want_occ=True, want_gt_occ=want_gt,
                               occ_dtype=torch.bool, voxel_dims=self.voxel_dims, bank_rider=bank_rider)
 
-    def rides(self) -> bool:
-        """K2 can ride in K1's first launch: a 9^3 bank (the prepared contraction) and the n-mode occupancy path"""
+    def rides(self, planes: int = 1) -> bool:
+        """K2 can ride in K1's first launch: a 9^3 bank and the occupancy fast path (n-mode or voxel-size mode)"""
         from . import _hip as h
-        return (self.overlap_bank and self.voxel_dims is None and self.model.kernel_size_of_bank() == (9, 9, 9)
-                and not self.model.fused_forward
-                and h.occupancy_supported(tuple(int(v) for v in self.voxelgrid_dims), 1))
+        return (self.overlap_bank and self.model.kernel_size_of_bank() == (9, 9, 9)
+                and h.occupancy_supported(tuple(int(v) for v in self.voxelgrid_dims), planes))
 
     def _finish(self, out, grids, batch, want_gt):
         if self.per_point:
@@ -119,7 +118,7 @@ class ScenePipeline:
         # inference: the module's own no-grad forward (scene_net.py), with K2 forked beside K1
         with torch.no_grad():
             dev = batch.pts.device
-            if self.rides() and not want_gt:
+            if self.rides(2 if want_gt else 1):
                 # K2 as riders of K1's first launch ([measured] forked onto a side stream it still cost the main stream
                 # 10.8 of its 12.4 serial microseconds: an event record and a wait)
                 _, _, bank, prep = rider = model.bank_rider(dev)
@@ -127,7 +126,11 @@ class ScenePipeline:
                 grids = self.voxelize(batch, want_gt, bank_rider=rider)
                 if not grids.rider_done:   # (the voxelisation took a path without the rider: K2 as its own launch)
                     bank, prep = model.compute_bank_prepared(dev)
-                out = model.contract_prepared(grids.occ, bank, lam, prep)[1]
+                x = grids.occ
+                if model.fused_forward and _hip.conv_fused_supported(x, model.kernel_size_of_bank()):
+                    out = _hip.conv_fused(x, bank, lam, out_dtype=model.activation_dtype or torch.float32)
+                else:
+                    out = model.contract_prepared(x, bank, lam, prep)[1]
                 return self._finish(out, grids, batch, want_gt)
             bank, lam, prep, join = self.bank_beside(dev)
             grids = self.voxelize(batch, want_gt)

@@ -113,8 +113,10 @@ def voxelize_batch(batch: PointBatch, voxelgrid_dims: Sequence[int] = (64, 64, 6
             # 120 k points at 128^3 against 0.58 ms in n-mode)
             occ, gt_occ, flags, dropped, desc, dims, status, _ = _hip.voxel_occupancy_sized(
                 batch.pts, batch.labels if want_t else None, batch.offsets, voxel_dims, (nx, ny, nz),
-                _labels_list(keep_labels) if want_t else (), want_gt_occ=want_gt_occ, out_dtype=occ_dtype)
-            return VoxelGrids(None, None, None, None, occ, gt_occ, desc, dropped, flags, dims, status)
+                _labels_list(keep_labels) if want_t else (), want_gt_occ=want_gt_occ, out_dtype=occ_dtype,
+                bank_rider=bank_rider)
+            return VoxelGrids(None, None, None, None, occ, gt_occ, desc, dropped, flags, dims, status,
+                              rider_done=bank_rider is not None)
         bbox = _hip.voxel_bbox(batch.pts, batch.offsets)
         desc, dims, status = _hip.voxel_desc_sized(bbox, voxel_dims, (nx, ny, nz))
         counts, towers, dropped = _hip.voxel_scatter(batch.pts, batch.labels if want_t else None, batch.offsets, desc,

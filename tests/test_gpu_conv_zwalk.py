@@ -233,8 +233,10 @@ def test_bank_riding_in_the_voxelisation_launch(hip_device, geneo_num):
 
 
 def test_pipeline_with_the_bank_forked_beside_the_voxelisation(hip_device):
-    """ScenePipeline(overlap_bank=True): K2 on a side stream next to K1, joined before K3 -- the same bits as the serial
-    pass, for the 16-kernel contraction and for the forward through linearity, eagerly and replayed from a hipGraph."""
+    """ScenePipeline(overlap_bank=True): K2 off the critical path -- riding in K1's first launch (9^3 banks; the side-stream
+    fork of bank_beside otherwise) -- gives the same bits as the serial pass, for the 16-kernel contraction and for the
+    forward through linearity, eagerly and replayed from a hipGraph; so does the fork itself (bank_beside, still the path of
+    other kernel extents)."""
     from scene_net_amd.synthetic import synthetic_tile
     model = _bench_model(hip_device)
     tiles = [synthetic_tile(i, 50_000)[0] for i in range(4)]
@@ -249,6 +251,13 @@ def test_pipeline_with_the_bank_forked_beside_the_voxelisation(hip_device):
             replayed = cap.replay().clone()
         assert all(torch.equal(serial, f) for f in forked)
         assert torch.equal(serial, replayed)
+        with torch.no_grad():   # the fork, by hand
+            bank, lam, prep, join = pipe.bank_beside(hip_device)
+            grids = pipe.voxelize(batch)
+            join()
+            by_fork = (_hip.conv_fused(grids.occ, bank, lam) if fused
+                       else model.contract_prepared(grids.occ, bank, lam, prep)[1])
+        assert torch.equal(serial, by_fork)
     model.fused_forward = True
     assert _hip.conv_i8_spin_timeouts() == 0
 
