@@ -14,10 +14,10 @@ model = model.to(dev)
 tiles, labels = zip(*[synthetic_tile(i, 100_000) for i in range(32)])
 batch = sna.PointBatch.from_tiles(tiles, labels, device=dev)
 pipe = sna.ScenePipeline(model, (64, 64, 64))
-def step():
-    bank, lam, prep, join = pipe.bank_beside(dev)
-    grids = pipe.voxelize(batch)
-    join()
+def step():   # (bench.py's step: K2 rides in K1's first launch)
+    _, _, bank, prep = rider = model.bank_rider(dev)
+    lam = model.effective_lambdas(dev)
+    grids = pipe.voxelize(batch, bank_rider=rider)
     return model.contract_prepared(grids.occ, bank, lam, prep)[1]
 import gc
 gc.collect(); gc.freeze()
