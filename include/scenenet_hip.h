@@ -314,8 +314,8 @@ int sn_voxel_occupancy_fused(const double* pts, const double* labels, const int6
                              sn_stream_t stream);
 
 /* sn_voxel_occupancy_fused with K2 riding in its first launch: the workgroups that build the 9 x 9 x 9 GENEO bank and the
- * int8 contraction's preparation blob (exactly sn_geneo_bank_prep's, without the coefficient side output: same arguments,
- * same bits) are extra grid rows of the bounding-box kernel, so the inference step has no launch, no stream fork and no
+ * int8 contraction's preparation blob (exactly sn_geneo_bank_prep's: the same arguments from `params` to `prep`, the same
+ * bits; with `lambdas` the effective coefficients ride too, as in a training forward's opener sn_geneo_bank_lambdas) are extra grid rows of the bounding-box kernel, so the inference step has no launch, no stream fork and no
  * event for K2 at all ([measured] the forked form left 10.8 of K2's 12.4 serial microseconds on the critical path).
  * Replaces, for the hot path, GENEO_Layer.compute_kernel x G (SCENE_Net.py:103-106, 322-324) next to
  * Voxelization.__call__ (torch_transforms.py:74-81). */
@@ -324,7 +324,8 @@ int sn_voxel_occupancy_fused_bank(const double* pts, const double* labels, const
                                   double* bbox, double* desc, uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype,
                                   int32_t* flags, int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws,
                                   const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
-                                  int32_t* status, void* prep, sn_stream_t stream);
+                                  int32_t* status, float* lambdas, const int32_t* order, int last, float* lambdas_out,
+                                  void* prep, sn_stream_t stream);
 
 /* sn_voxel_occupancy_fused in VOXEL-SIZE mode (voxelize_ply with size_x / size_y / size_z, utils/pcd_processing.py:365-367;
  * the mode SemanticKITTI uses, core/datasets/semKITTI.py:453-455): every tile's grid extents follow from its own bounding
@@ -346,7 +347,8 @@ int sn_voxel_occupancy_sized_bank(const double* pts, const double* labels, const
                                   uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype, int32_t* flags,
                                   int32_t* dropped, int32_t* counts_ws, int32_t* towers_ws, const float* params,
                                   const int32_t* kinds, int G, int kz, int kx, int ky, float* bank, int32_t* bank_status,
-                                  void* prep, sn_stream_t stream);
+                                  float* lambdas, const int32_t* order, int last, float* lambdas_out, void* prep,
+                                  sn_stream_t stream);
 
 
 /* Grid -> points: out[c, i] = grid[b(i), c, vz, vx, vy] for every point i of the batch, binned exactly as the

@@ -56,11 +56,11 @@ SYMBOLS = {
     "sn_voxel_occupancy_fused": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P,
                                          _P]),
     "sn_voxel_occupancy_fused_bank": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P,
-                                              _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+                                              _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "sn_voxel_occupancy_sized": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P,
                                          _P, _P, _P]),
     "sn_voxel_occupancy_sized_bank": (c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
-                                              _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+                                              _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "sn_voxel_prepare": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "sn_gather_points": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _I, ctypes.c_double, _P, _P]),
     "sn_grid_to_points": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -611,16 +611,24 @@ def voxel_occupancy_fused(pts, labels, offsets, n_xyz, regular: bool = True, kee
         rc = load().sn_voxel_occupancy_fused(*common, _stream())
         _check(rc, "sn_voxel_occupancy_fused")
     else:
-        params, kinds, bank, prep = bank_rider
-        G = params.shape[0]
-        if tuple(bank.shape) != (G, 9, 9, 9) or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
-            raise HipLibraryError("bank_rider: bank must be [G,9,9,9] f32 and prep SN_CONV_PREP_BYTES x ceil(G / 16) bytes")
-        rc = load().sn_voxel_occupancy_fused_bank(*common, _ptr(params, torch.float32, "params"),
-                                                  _ptr(kinds, torch.int32, "kinds"), G, 9, 9, 9,
-                                                  _ptr(bank, torch.float32, "bank"), None, _ptr(prep, torch.uint8, "prep"),
-                                                  _stream())
-        _check(rc, "sn_voxel_occupancy_fused_bank")
+        _check(load().sn_voxel_occupancy_fused_bank(*common, *_rider_args(bank_rider), _stream()),
+               "sn_voxel_occupancy_fused_bank")
     return occ, gt_occ, flags, dropped, desc, bbox
+
+
+def _rider_args(bank_rider):
+    """bank_rider = (params [G, SN_NPARAM] f32, kinds [G] i32, bank [G,9,9,9] f32 out, prep uint8 out) or, with the effective
+    coefficients riding too, (params, kinds, bank, prep, lambdas [G] f32 (refreshed in place), order [G] i32, last, lam_out [G]
+    f32 out) -> the C argument tail of the sn_voxel_occupancy_*_bank entries"""
+    params, kinds, bank, prep = bank_rider[:4]
+    lambdas, order, last, lam_out = bank_rider[4:] if len(bank_rider) > 4 else (None, None, 0, None)
+    G = params.shape[0]
+    if tuple(bank.shape) != (G, 9, 9, 9) or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
+        raise HipLibraryError("bank_rider: bank must be [G,9,9,9] f32 and prep SN_CONV_PREP_BYTES x ceil(G / 16) bytes")
+    return (_ptr(params, torch.float32, "params"), _ptr(kinds, torch.int32, "kinds"), G, 9, 9, 9,
+            _ptr(bank, torch.float32, "bank"), None, _ptr(lambdas, torch.float32, "lambdas"),
+            _ptr(order, torch.int32, "order"), int(last), _ptr(lam_out, torch.float32, "lam_out"),
+            _ptr(prep, torch.uint8, "prep"))
 
 
 @_on_tensor_device
@@ -658,15 +666,8 @@ def voxel_occupancy_sized(pts, labels, offsets, size_xyz: Sequence[float], n_xyz
     if bank_rider is None:
         _check(load().sn_voxel_occupancy_sized(*common, _stream()), "sn_voxel_occupancy_sized")
     else:   # (as voxel_occupancy_fused: K2 + the preparation ride in the first launch)
-        params, kinds, bank, prep = bank_rider
-        G = params.shape[0]
-        if tuple(bank.shape) != (G, 9, 9, 9) or prep.numel() < SN_CONV_PREP_BYTES * ((G + 15) // 16):
-            raise HipLibraryError("bank_rider: bank must be [G,9,9,9] f32 and prep SN_CONV_PREP_BYTES x ceil(G / 16) bytes")
-        rc = load().sn_voxel_occupancy_sized_bank(*common, _ptr(params, torch.float32, "params"),
-                                                  _ptr(kinds, torch.int32, "kinds"), G, 9, 9, 9,
-                                                  _ptr(bank, torch.float32, "bank"), None, _ptr(prep, torch.uint8, "prep"),
-                                                  _stream())
-        _check(rc, "sn_voxel_occupancy_sized_bank")
+        _check(load().sn_voxel_occupancy_sized_bank(*common, *_rider_args(bank_rider), _stream()),
+               "sn_voxel_occupancy_sized_bank")
     return occ, gt_occ, flags, dropped, desc, dims, status, bbox
 
 

@@ -241,7 +241,11 @@ struct BankRider {
     float* bank;
     int32_t* status;
     uint8_t* prep;
-    int G, nblocks;
+    float* lambdas;          // nullable: the effective coefficients ride too (one more workgroup; sn_geneo_bank_prep's)
+    const int32_t* order;
+    float* lambdas_out;
+    int last;
+    int G, nblocks;          // nblocks = 16 ceil(G / 16) (+ 1 with lambdas)
 };
 
 template <bool kAligned>
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(kThreads) void bbox_partial_bank_kernel(const doubl
         __shared__ float bank_lds[729 + 9 + 1 + 8 + 1];
         const int g = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
         if (g < r.nblocks)
-            geneo_bank_body<true>(bank_lds, g, threadIdx.x, r.params, r.kinds, 9, 9, 9, r.bank, r.status, r.G, nullptr,
-                                  nullptr, 0, nullptr, r.prep);
+            geneo_bank_body<true>(bank_lds, g, threadIdx.x, r.params, r.kinds, 9, 9, 9, r.bank, r.status, r.G, r.lambdas,
+                                  r.order, r.last, r.lambdas_out, r.prep);
         return;
     }
     bbox_partial_body<kAligned>(pts, offsets, partial, (int)blockIdx.y - rider_rows);
@@ -1227,9 +1231,10 @@ extern "C" int sn_voxel_occupancy_fused(const double* pts, const double* labels,
 
 // the bounding-box launch of the fused entry points, with K2's workgroups as riders when a bank is handed in
 static int check_rider(const char* who, const float* params, const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
-                       void* prep) {
+                       const float* lambdas, const int32_t* order, int last, const float* lambdas_out, void* prep) {
     if (!params || !kinds || !bank || !prep) return sn::fail(SN_ERR_INVALID_ARG, "%s: null bank argument", who);
-    if (G <= 0) return sn::fail(SN_ERR_INVALID_ARG, "%s: bad G", who);
+    if (lambdas && (!order || !lambdas_out)) return sn::fail(SN_ERR_INVALID_ARG, "%s: lambdas without order / out", who);
+    if (G <= 0 || (lambdas && (last < 0 || last >= G))) return sn::fail(SN_ERR_INVALID_ARG, "%s: bad G / last", who);
     if (kz != 9 || kx != 9 || ky != 9)
         return sn::fail(SN_ERR_UNSUPPORTED, "%s: the prepared contraction serves 9 x 9 x 9 kernels (got %d,%d,%d)", who, kz, kx,
                         ky);
@@ -1238,8 +1243,10 @@ static int check_rider(const char* who, const float* params, const int32_t* kind
 }
 
 static void launch_bbox_with_riders(const double* pts, const int64_t* offsets, double* partial_ws, int B, const float* params,
-                                    const int32_t* kinds, int G, float* bank, int32_t* status, void* prep, hipStream_t s) {
-    BankRider r{params, kinds, bank, status, static_cast<uint8_t*>(prep), G, 16 * ((G + 15) / 16)};
+                                    const int32_t* kinds, int G, float* bank, int32_t* status, float* lambdas,
+                                    const int32_t* order, int last, float* lambdas_out, void* prep, hipStream_t s) {
+    BankRider r{params, kinds, bank, status, static_cast<uint8_t*>(prep), lambdas, order, lambdas_out, last, G,
+                16 * ((G + 15) / 16) + (lambdas ? 1 : 0)};
     const int extra_rows = (r.nblocks + SN_BBOX_PARTS - 1) / SN_BBOX_PARTS;
     dim3 grid(SN_BBOX_PARTS, B + extra_rows);
     if (aligned16(pts))
@@ -1255,14 +1262,18 @@ extern "C" int sn_voxel_occupancy_fused_bank(const double* pts, const double* la
                                              void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
                                              int32_t* counts_ws, int32_t* towers_ws, const float* params,
                                              const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
-                                             int32_t* status, void* prep, sn_stream_t stream) {
+                                             int32_t* status, float* lambdas, const int32_t* order, int last,
+                                             float* lambdas_out, void* prep, sn_stream_t stream) {
     if (!pts || !offsets || !partial_ws || !desc)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: null pointer");
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused_bank: non-positive extent (B=%d n=%d,%d,%d)", B, nx,
                         ny, nz);
-    if (int rc = check_rider("sn_voxel_occupancy_fused_bank", params, kinds, G, kz, kx, ky, bank, prep)) return rc;
-    launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, status, prep, sn::as_stream(stream));
+    if (int rc = check_rider("sn_voxel_occupancy_fused_bank", params, kinds, G, kz, kx, ky, bank, lambdas, order, last,
+                             lambdas_out, prep))
+        return rc;
+    launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, status, lambdas, order, last, lambdas_out,
+                            prep, sn::as_stream(stream));
     if (int rc = sn::check_launch("sn_voxel_occupancy_fused_bank(bbox + bank)")) return rc;
     return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
                           out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
@@ -1274,8 +1285,8 @@ static int occupancy_sized_impl(const char* who, const double* pts, const double
                                 int n_keep, double* partial_ws, double* bbox, double* desc, int32_t* dims, int32_t* status,
                                 uint32_t* bits_ws, void* occ, void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
                                 int32_t* counts_ws, int32_t* towers_ws, bool rider, const float* params,
-                                const int32_t* kinds, int G, float* bank, int32_t* bank_status, void* prep,
-                                sn_stream_t stream) {
+                                const int32_t* kinds, int G, float* bank, int32_t* bank_status, float* lambdas,
+                                const int32_t* order, int last, float* lambdas_out, void* prep, sn_stream_t stream) {
     if (!pts || !offsets || !partial_ws || !desc || !dims || !size_xyz_host)
         return sn::fail(SN_ERR_INVALID_ARG, "%s: null pointer", who);
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -1287,7 +1298,8 @@ static int occupancy_sized_impl(const char* who, const double* pts, const double
     }
     hipStream_t s = sn::as_stream(stream);
     if (rider) {
-        launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, bank_status, prep, s);
+        launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, bank_status, lambdas, order, last,
+                                lambdas_out, prep, s);
     } else {
         dim3 grid(SN_BBOX_PARTS, B);
         if (aligned16(pts))
@@ -1314,7 +1326,7 @@ extern "C" int sn_voxel_occupancy_sized(const double* pts, const double* labels,
     return occupancy_sized_impl("sn_voxel_occupancy_sized", pts, labels, offsets, B, size_xyz_host, nx, ny, nz,
                                 keep_labels_host, n_keep, partial_ws, bbox, desc, dims, status, bits_ws, occ, gt_occ, out_dtype,
                                 flags, dropped, counts_ws, towers_ws, false, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
-                                stream);
+                                nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int sn_voxel_occupancy_sized_bank(const double* pts, const double* labels, const int64_t* offsets, int B,
@@ -1324,11 +1336,15 @@ extern "C" int sn_voxel_occupancy_sized_bank(const double* pts, const double* la
                                              void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped,
                                              int32_t* counts_ws, int32_t* towers_ws, const float* params,
                                              const int32_t* kinds, int G, int kz, int kx, int ky, float* bank,
-                                             int32_t* bank_status, void* prep, sn_stream_t stream) {
-    if (int rc = check_rider("sn_voxel_occupancy_sized_bank", params, kinds, G, kz, kx, ky, bank, prep)) return rc;
+                                             int32_t* bank_status, float* lambdas, const int32_t* order, int last,
+                                             float* lambdas_out, void* prep, sn_stream_t stream) {
+    if (int rc = check_rider("sn_voxel_occupancy_sized_bank", params, kinds, G, kz, kx, ky, bank, lambdas, order, last,
+                             lambdas_out, prep))
+        return rc;
     return occupancy_sized_impl("sn_voxel_occupancy_sized_bank", pts, labels, offsets, B, size_xyz_host, nx, ny, nz,
                                 keep_labels_host, n_keep, partial_ws, bbox, desc, dims, status, bits_ws, occ, gt_occ, out_dtype,
-                                flags, dropped, counts_ws, towers_ws, true, params, kinds, G, bank, bank_status, prep, stream);
+                                flags, dropped, counts_ws, towers_ws, true, params, kinds, G, bank, bank_status, lambdas, order,
+                                last, lambdas_out, prep, stream);
 }
 
 extern "C" int sn_gather_points(const void* grid, int dtype, int channels, const double* pts, const int64_t* offsets,

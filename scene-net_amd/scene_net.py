@@ -286,6 +286,27 @@ class SceneNet(nn.Module):
             self.__dict__["_prepared_bufs"] = bufs
         return params, kinds, bufs[0], bufs[1]
 
+    def train_rider(self, device=None):
+        """The opener of a TRAINING forward -- bank + effective coefficients, sn_geneo_bank_lambdas -- as riders of the
+        voxelisation's first launch: returns (rider, (bank, lam)); hand `rider` to voxelize_batch(bank_rider=...) and
+        `(bank, lam)` to forward(x, bank_lam=...) of the same step.  Reads the flat parameter buffer the nn.Parameters
+        alias (as the autograd function would) and refreshes the frozen coefficient in place.  9 x 9 x 9 banks."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.kernel_size_of_bank() != (9, 9, 9):
+            raise _hip.HipLibraryError("train_rider serves 9 x 9 x 9 kernels")
+        flat, meta, _ = self._flat_sync(device)
+        G = meta["G"]
+        n = G * _hip.SN_NPARAM
+        bufs = self.__dict__.get("_train_rider_bufs")
+        if bufs is None or bufs[0].device != device or bufs[0].shape[0] != G:
+            bufs = (torch.empty((G, 9, 9, 9), dtype=torch.float32, device=device),
+                    torch.zeros(_hip.SN_CONV_PREP_BYTES * ((G + 15) // 16), dtype=torch.uint8, device=device),
+                    torch.empty(G, dtype=torch.float32, device=device))
+            self.__dict__["_train_rider_bufs"] = bufs
+        bank, prep, lam = bufs
+        rider = (flat[:n].view(G, _hip.SN_NPARAM), meta["kinds"], bank, prep, flat[n:], meta["order"], meta["last"], lam)
+        return rider, (bank, lam)
+
     def contract_prepared(self, x: torch.Tensor, bank: torch.Tensor, lam: torch.Tensor, prep: torch.Tensor,
                           want_act: bool = False, out_dtype: Optional[torch.dtype] = None):
         """sn_conv_bank_prepared on (bank, lam, prep) of THIS model's current parameters -> (act | None, out).  The walk's
@@ -364,11 +385,12 @@ class SceneNet(nn.Module):
         self._flat_meta.update(mask_params=mp.to(device), mask_cvx=mc.to(device), mask_all=(mp + mc).to(device))
         return flat, self._flat_meta, leaves
 
-    def forward(self, x: torch.Tensor, return_bank_activations: bool = False):
+    def forward(self, x: torch.Tensor, return_bank_activations: bool = False, bank_lam=None):
         """x [B,1,Z,X,Y] on a HIP device -> relu(tanh(sum_i lambda_i conv3d(x, K_i))) [B,1,Z,X,Y], same dtype
         (f32 for bool / u8 input).  With return_bank_activations=True also returns conv [B,G,Z,X,Y]
         (SCENE_Net.py:325; not differentiable).  Under autograd the output carries the graph to every trainable
-        scalar: backward = sn_conv_corr + sn_geneo_bank_bwd."""
+        scalar: backward = sn_conv_corr + sn_geneo_bank_bwd.  bank_lam: (bank, lam) of train_rider() -- built from the
+        current parameters by this step's voxelisation launch -- instead of the forward's own opener."""
         if not x.is_cuda:
             raise _hip.HipLibraryError("SceneNet.forward runs on the HIP device only (no CPU fallback): move x to cuda")
         ks = self.kernel_size_of_bank()
@@ -380,7 +402,7 @@ class SceneNet(nn.Module):
             live.packed, live.leaves = weakref.ref(P), tuple(params)
             live.mask_params, live.mask_cvx, live.mask_all = meta["mask_params"], meta["mask_cvx"], meta["mask_all"]
             out, act = _GeneoForwardFn.apply(x.contiguous(), P, flat, meta, ks, return_bank_activations,
-                                             bool(self.fused_forward), self.activation_dtype)
+                                             bool(self.fused_forward), self.activation_dtype, bank_lam)
             live.versions = tuple(p._version for p in params)
             self._lambda_cache = None  # lambdas_dict[last_lambda] was refreshed in place (SCENE_Net.py:333)
             return (out, act) if return_bank_activations else out
@@ -410,11 +432,14 @@ class _GeneoForwardFn(torch.autograd.Function):
     coefficient sn_effective_lambdas refreshes in place."""
 
     @staticmethod
-    def forward(ctx, x, P, flat, meta, kernel_size, want_act, fused=False, act_dtype=None):
+    def forward(ctx, x, P, flat, meta, kernel_size, want_act, fused=False, act_dtype=None, bank_lam=None):
         G = meta["G"]
         n = G * _hip.SN_NPARAM
         p = flat[:n].view(G, _hip.SN_NPARAM)
-        bank, lam = _hip.geneo_bank_lambdas(p, meta["kinds"], kernel_size, flat[n:], meta["order"], meta["last"])
+        if bank_lam is not None:   # (SceneNet.train_rider: the same kernels' code ran in the voxelisation's first launch)
+            bank, lam = bank_lam
+        else:
+            bank, lam = _hip.geneo_bank_lambdas(p, meta["kinds"], kernel_size, flat[n:], meta["order"], meta["last"])
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
         if fused and not want_act and _hip.conv_fused_supported(x, kernel_size):
             if act_dtype is not None:   # bf16 activation storage (SceneNet.activation_dtype): the linear forward writes it
@@ -443,7 +468,7 @@ class _GeneoForwardFn(torch.autograd.Function):
         # generator Jacobians and the packing into gP: one launch
         gP = torch.empty_like(P)
         _hip.geneo_backward(P[:n].view(G, _hip.SN_NPARAM), kinds, ctx.kernel_size, bank, lam, C, ctx.last, gP)
-        return None, gP, None, None, None, None, None, None
+        return None, gP, None, None, None, None, None, None, None
 
 
 class SCENE_Net(SceneNet):

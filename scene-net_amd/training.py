@@ -50,6 +50,21 @@ def allreduce_flat_grads(params: Iterable[torch.Tensor], group=None, average: bo
     return flat.numel()
 
 
+def voxelize_and_forward(pipe: ScenePipeline, batch: PointBatch):
+    """(grids, pred) of a training step: voxelise with the ground-truth plane, then the module's forward under autograd.
+    When the bank is 9 x 9 x 9 the forward's opener (bank + effective coefficients, sn_geneo_bank_lambdas) rides in the
+    voxelisation's first launch (SceneNet.train_rider) instead of being a launch of its own."""
+    model = pipe.model
+    rides = (pipe.rides(2) and torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+             and batch.pts.is_cuda)
+    if not rides:
+        grids = pipe.voxelize(batch, want_gt=True)
+        return grids, model(grids.occ)
+    rider, bank_lam = model.train_rider(batch.pts.device)
+    grids = pipe.voxelize(batch, want_gt=True, bank_rider=rider)
+    return grids, model(grids.occ, bank_lam=bank_lam if grids.rider_done else None)
+
+
 class CapturedTrainingStep:
     """step = zero_grad; grids = pipe.voxelize(batch, want_gt=True); loss = criterion(model(grids.occ), grids.gt_occ,
     cvx coefficients, GENEO parameters); loss.backward(); [all-reduce of the gradients over `group`]; optimizer.step().
@@ -68,8 +83,7 @@ class CapturedTrainingStep:
 
         def front():
             optimizer.zero_grad(set_to_none=True)
-            grids = pipe.voxelize(batch, want_gt=True)
-            pred = model(grids.occ)
+            grids, pred = voxelize_and_forward(pipe, batch)
             if loss_fn is not None:
                 loss = loss_fn(pred, grids)
             else:

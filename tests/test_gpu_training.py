@@ -223,3 +223,69 @@ def test_captured_training_step_api(hip_device):
     assert loss_e.item() == losses[-1]
     for (n, a), (_, b) in zip(model_e.named_parameters(), model.named_parameters()):
         assert torch.equal(a.detach(), b.detach()), n
+
+
+def test_training_step_with_the_opener_riding_in_the_voxelisation(hip_device):
+    """9 x 9 x 9 bank: training.voxelize_and_forward hands the forward's opener (bank + effective coefficients) to the
+    voxelisation's first launch (SceneNet.train_rider -> sn_voxel_occupancy_fused_bank with lambdas) -- the same bank, the
+    same coefficients, the same refreshed frozen coefficient, hence the same losses and parameters, bit for bit, as the
+    step whose forward opens with sn_geneo_bank_lambdas; eagerly and as a CapturedTrainingStep."""
+    from scene_net_amd.synthetic import synthetic_tile
+    from scene_net_amd.training import voxelize_and_forward
+    tiles, labels = zip(*[synthetic_tile(t, 20_000) for t in range(2)])
+
+    def build():
+        torch.manual_seed(5)
+        model = sna.SceneNet({"cy": 2, "cone": 2, "neg": 1}, (9, 9, 9)).to(hip_device)
+        with torch.no_grad():
+            for n in model.geneos:
+                model.lambdas_dict[f"lambda_{n}"].mul_(0.1)
+        batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+        pipe = sna.ScenePipeline(model, (32, 32, 32), keep_labels=[15.0])
+        gt = pipe.voxelize(batch, want_gt=True).gt_occ
+        crit = sna.GENEO_Tversky_Loss(targets=gt.float(), weighting_scheme_path=None, save_weighting_scheme=False)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2, capturable=True)
+        return model, batch, pipe, crit, opt
+
+    # the rider's outputs against the forward's own opener, on the same parameters
+    model, batch, pipe, crit, opt = build()
+    assert pipe.rides(2)
+    flat, meta, _ = model._flat_sync(hip_device)
+    n = meta["G"] * _hip.SN_NPARAM
+    lam_before = flat[n:].clone()
+    bank_o, lam_o = _hip.geneo_bank_lambdas(flat[:n].view(meta["G"], _hip.SN_NPARAM), meta["kinds"], (9, 9, 9),
+                                            flat[n:].clone(), meta["order"], meta["last"])
+    rider, (bank_r, lam_r) = model.train_rider(hip_device)
+    grids = pipe.voxelize(batch, want_gt=True, bank_rider=rider)
+    assert grids.rider_done and torch.equal(bank_r, bank_o) and torch.equal(lam_r, lam_o)
+    assert torch.equal(flat[n:], torch.where(torch.arange(meta["G"], device=hip_device) == meta["last"], lam_o, lam_before))
+
+    def serial_steps(k):
+        model_e, batch_e, pipe_e, crit_e, opt_e = build()
+        for _ in range(k):
+            opt_e.zero_grad(set_to_none=True)
+            g = pipe_e.voxelize(batch_e, want_gt=True)
+            loss = crit_e(model_e(g.occ), g.gt_occ, model_e.get_cvx_coefficients(), model_e.get_geneo_params())
+            loss.backward()
+            opt_e.step()
+        return model_e, loss
+
+    model_r, batch_r, pipe_r, crit_r, opt_r = build()
+    for _ in range(4):
+        opt_r.zero_grad(set_to_none=True)
+        g, pred = voxelize_and_forward(pipe_r, batch_r)
+        loss_r = crit_r(pred, g.gt_occ, model_r.get_cvx_coefficients(), model_r.get_geneo_params())
+        loss_r.backward()
+        opt_r.step()
+    model_e, loss_e = serial_steps(4)
+    assert loss_r.item() == loss_e.item()
+    for (nm, a), (_, b) in zip(model_e.named_parameters(), model_r.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), nm
+
+    model_c, batch_c, pipe_c, crit_c, opt_c = build()
+    cap = sna.CapturedTrainingStep(pipe_c, crit_c, opt_c, batch_c, warmup=2)
+    losses = [cap.replay().item() for _ in range(3)]
+    model_e, loss_e = serial_steps(2 + 3)
+    assert loss_e.item() == losses[-1]
+    for (nm, a), (_, b) in zip(model_e.named_parameters(), model_c.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), nm

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scene_net_amd as sna  # noqa: E402
 from scene_net_amd import _hip  # noqa: E402
 from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile  # noqa: E402
+from scene_net_amd.training import voxelize_and_forward  # noqa: E402
 
 
 def timed(fn, iters, warm=2, spin_ms=150.0):
@@ -77,8 +78,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        g = pipe.voxelize(batch, want_gt=True)
-        out = model(g.occ)
+        g, out = voxelize_and_forward(pipe, batch)   # (the forward's opener rides in the voxelisation's first launch)
         loss = crit(out, g.gt_occ, model.get_cvx_coefficients(), model.get_geneo_params())
         loss.backward()
         opt.step()
