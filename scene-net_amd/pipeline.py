@@ -66,8 +66,9 @@ class ScenePipeline:
         self.voxel_dims = None if voxel_dims is None else tuple(float(v) for v in voxel_dims)
         self.per_point = bool(per_point)
         self.tau = tau
-        # K2 (bank builder + the contraction's preparation) reads only the model's scalars: it runs on a forked stream
-        # beside K1 and is joined in front of K3 (a parallel branch when the pass is captured into a hipGraph)
+        # K2 (bank builder + the contraction's preparation) reads only the model's scalars.  overlap_bank: it leaves the
+        # critical path -- as riders of K1's first launch for a 9^3 bank (rides()), else on a forked stream beside K1,
+        # joined in front of K3 (bank_beside: a parallel branch when the pass is captured into a hipGraph)
         self.overlap_bank = bool(overlap_bank)
         self._side = None
 
@@ -115,7 +116,7 @@ class ScenePipeline:
             grids = self.voxelize(batch, want_gt)
             out = model(grids.occ)
             return self._finish(out, grids, batch, want_gt)
-        # inference: the module's own no-grad forward (scene_net.py), with K2 forked beside K1
+        # inference: the module's own no-grad forward (scene_net.py), with K2 off the critical path
         with torch.no_grad():
             dev = batch.pts.device
             if self.rides(2 if want_gt else 1):

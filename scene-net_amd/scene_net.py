@@ -254,7 +254,8 @@ class SceneNet(nn.Module):
     def compute_bank_prepared(self, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """(bank [G,9,9,9] f32, prep uint8): compute_bank and the int8 contraction's per-bank preparation in ONE launch
         (sn_geneo_bank_prep), written into two buffers the model keeps per device -- nothing is allocated per call, so
-        the launch can sit on a side stream next to the voxelisation (ScenePipeline).  9 x 9 x 9 kernels only.  The
+        the launch can sit on a side stream next to the voxelisation (ScenePipeline.bank_beside; bank_rider() is the form
+        without any launch of its own).  9 x 9 x 9 kernels only.  The
         reference rebuilds its kernels at every forward (SCENE_Net.py:322-327); so does this."""
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.kernel_size_of_bank() != (9, 9, 9):
