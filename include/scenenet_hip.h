@@ -459,6 +459,17 @@ int sn_param_penalty(const float* P, const int8_t* mask, int N, float weight, in
 int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
                      const float* ranges, int H, const double* coef, const double* upstream, void* grad_pred,
                      sn_stream_t stream);
+/* The same two with what a float32 criterion needs to stay free of cast launches (a training step replayed from a hipGraph
+ * pays ~4 us of GPU time for every one-element kernel): sn_loss_forward_m also writes the five losses rounded to float32
+ * (loss_f32 [5], nullable); sn_loss_backward_u takes the upstream scalar as SN_F64 or SN_F32. */
+int sn_loss_forward_m(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                      const float* ranges, const float* bin_w, int H, int terms, double mse_weight, double tversky_alpha,
+                      double tversky_beta, double focal_gamma, double tversky_smooth, double dice_smooth, double* parts_ws,
+                      double* stats, double* loss, float* loss_f32, double* coef, sn_stream_t stream);
+int sn_loss_backward_u(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                       const float* ranges, int H, const double* coef, const void* upstream, int up_dtype, void* grad_pred,
+                       sn_stream_t stream);
+
 
 #ifdef __cplusplus
 }

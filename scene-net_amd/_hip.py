@@ -76,6 +76,9 @@ SYMBOLS = {
                         + [_P, _P, _P, _P, _P]),
     "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
     "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
+    "sn_loss_forward_m": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
+                          + [_P, _P, _P, _P, _P, _P]),
+    "sn_loss_backward_u": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _I, _P, _P]),
 }
 SN_CONV_PREP_BYTES = 16384
 SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE, SN_LOSS_WBCE = 1, 2, 4, 8
@@ -782,8 +785,8 @@ def loss_parts(n_per: int) -> int:
 def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int,
                  mse_weight: float = 1.0, tversky_alpha: float = 0.5, tversky_beta: float = 1.0,
                  focal_gamma: float = 1.0, tversky_smooth: float = 1.0, dice_smooth: float = 1.0):
-    """sn_loss_forward on pred/gt [B, ...] (same shape).  Returns (loss [5] f64 = {total, wmse, focal tversky, dice,
-    weighted bce}, stats [B, 3H+5] f64, coef f64 for loss_backward)."""
+    """sn_loss_forward_m on pred/gt [B, ...] (same shape).  Returns (loss [5] f64 = {total, wmse, focal tversky, dice,
+    weighted bce}, stats [B, 3H+5] f64, coef f64 for loss_backward, loss32 [5] f32 = the same five rounded once)."""
     if pred.shape != gt.shape:
         raise HipLibraryError(f"pred {tuple(pred.shape)} and gt {tuple(gt.shape)} must have the same shape")
     B = int(pred.shape[0])
@@ -793,27 +796,32 @@ def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin
     ws = torch.empty((B * loss_parts(n_per) * (3 * H + 5),), dtype=torch.float64, device=dev)
     stats = torch.empty((B, 3 * H + 5), dtype=torch.float64, device=dev)
     loss = torch.empty((5,), dtype=torch.float64, device=dev)
+    loss32 = torch.empty((5,), dtype=torch.float32, device=dev)
     coef = torch.empty((2 * SN_LOSS_MAX_BINS + 3 * B,), dtype=torch.float64, device=dev)
-    rc = load().sn_loss_forward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
-                                n_per, _ptr(ranges, torch.float32, "ranges"), _ptr(bin_w, torch.float32, "bin_w"), H,
-                                int(terms), float(mse_weight), float(tversky_alpha), float(tversky_beta),
-                                float(focal_gamma), float(tversky_smooth), float(dice_smooth), _ptr(ws), _ptr(stats),
-                                _ptr(loss), _ptr(coef), _stream())
+    rc = load().sn_loss_forward_m(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
+                                  n_per, _ptr(ranges, torch.float32, "ranges"), _ptr(bin_w, torch.float32, "bin_w"), H,
+                                  int(terms), float(mse_weight), float(tversky_alpha), float(tversky_beta),
+                                  float(focal_gamma), float(tversky_smooth), float(dice_smooth), _ptr(ws), _ptr(stats),
+                                  _ptr(loss), _ptr(loss32), _ptr(coef), _stream())
     _check(rc, "sn_loss_forward")
-    return loss, stats, coef
+    return loss, stats, coef, loss32
 
 
 @_on_tensor_device
 def loss_backward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, coef: torch.Tensor,
                   upstream: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dL/dpred (pred's dtype and shape) from the coefficients of loss_forward (sn_loss_backward)."""
+    """dL/dpred (pred's dtype and shape) from the coefficients of loss_forward (sn_loss_backward_u); upstream: a
+    one-element f64 or f32 tensor (or None = 1)."""
     B = int(pred.shape[0])
     n_per = pred.numel() // max(B, 1)
     grad = torch.empty_like(pred)
-    rc = load().sn_loss_backward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
-                                 n_per, _ptr(ranges, torch.float32, "ranges"), int(ranges.numel()),
-                                 _ptr(coef, torch.float64, "coef"), _ptr(upstream, torch.float64, "upstream"),
-                                 _ptr(grad), _stream())
+    if upstream is not None and upstream.dtype not in (torch.float64, torch.float32):
+        upstream = upstream.to(torch.float64)
+    up_dt = _DT[upstream.dtype] if upstream is not None else SN_F64
+    rc = load().sn_loss_backward_u(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
+                                   n_per, _ptr(ranges, torch.float32, "ranges"), int(ranges.numel()),
+                                   _ptr(coef, torch.float64, "coef"), _ptr(upstream, None, "upstream"), up_dt,
+                                   _ptr(grad), _stream())
     _check(rc, "sn_loss_backward")
     return grad
 

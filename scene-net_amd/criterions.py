@@ -40,16 +40,20 @@ class _DenseLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, ranges, bin_w, terms, cfg):
         pred_c, gt_c = pred.contiguous(), gt.contiguous()
-        loss, stats, coef = _hip.loss_forward(pred_c, gt_c, ranges, bin_w, terms, **cfg)
+        loss, stats, coef, loss32 = _hip.loss_forward(pred_c, gt_c, ranges, bin_w, terms, **cfg)
         ctx.save_for_backward(pred_c, gt_c, ranges, coef)
         ctx.mark_non_differentiable(stats)
-        # the loss scalar: pred's float dtype; fp32 for bf16 predictions (bf16 is activation storage only)
-        return loss[0].to(pred.dtype if pred.dtype in (torch.float32, torch.float64) else torch.float32), stats
+        ctx.set_materialize_grads(False)   # (no zero-filled gradient for `stats`: a launch per step for nothing)
+        # the loss scalar: pred's float dtype; fp32 for bf16 predictions (bf16 is activation storage only) -- the kernel
+        # writes both roundings, the cast is not a launch of its own
+        return (loss[0] if pred.dtype == torch.float64 else loss32[0]), stats
 
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
+        if g_loss is None:
+            return None, None, None, None, None, None
         pred, gt, ranges, coef = ctx.saved_tensors
-        up = g_loss.detach().to(torch.float64).reshape(1).contiguous()
+        up = g_loss.detach().reshape(1)   # f64 or f32: read as it is (sn_loss_backward_u)
         return _hip.loss_backward(pred, gt, ranges, coef, up), None, None, None, None, None
 
 

@@ -243,7 +243,8 @@ constexpr int kCombineThreads = 1024;
 __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const double* __restrict__ parts, int B, int nparts,
                                                                 long n_per, int H, const float* __restrict__ bin_w,
                                                                 LossCfg cfg, double* __restrict__ stats,
-                                                                double* __restrict__ loss, double* __restrict__ coef) {
+                                                                double* __restrict__ loss, double* __restrict__ coef,
+                                                                float* __restrict__ loss32) {
     __shared__ double tot[3 * kMaxBins + 5];
     __shared__ double dice_part[kCombineThreads];
     const int nstat = 3 * H + 5;
@@ -342,6 +343,10 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
         loss[2] = focal;
         loss[3] = dice;
         loss[4] = wbce;
+        if (loss32) {   // (the same five numbers rounded once: what a float32 criterion returns, without a cast launch)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) loss32[k] = (float)loss[k];
+        }
     }
     __syncthreads();
     if (threadIdx.x < kMaxBins) {
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
                                                              long n_per, long span, const float* __restrict__ ranges,
                                                              int H, const double* __restrict__ coef,
                                                              const double* __restrict__ upstream,
+                                                             const float* __restrict__ upstream32,
                                                              PT* __restrict__ grad) {
     using C = typename ComputeOf<PT>::type;  // gradient arithmetic in pred's dtype (bf16 storage: fp32)
     __shared__ C ck[kMaxBins], ek[kMaxBins];
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
     PT* g = grad + (size_t)b * n_per;
     BinOf<GT> bin;
     bin.init(ranges, H);
-    const double up = upstream ? *upstream : 1.0;
+    const double up = upstream ? *upstream : (upstream32 ? (double)*upstream32 : 1.0);
     const C A = (C)(coef[2 * kMaxBins + 3 * b] * up), Bc = (C)(coef[2 * kMaxBins + 3 * b + 1] * up),
             Cc = (C)(coef[2 * kMaxBins + 3 * b + 2] * up);
     C c0 = 0, c1 = 0, e0 = 0, e1 = 0;
@@ -523,11 +529,11 @@ long span_of(int64_t n_per, int nparts) {
         }                                                                                                         \
     } while (0)
 
-extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
-                               const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
-                               double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
-                               double dice_smooth, double* parts_ws, double* stats, double* loss, double* coef,
-                               sn_stream_t stream) {
+extern "C" int sn_loss_forward_m(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                 const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                                 double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                                 double dice_smooth, double* parts_ws, double* stats, double* loss, float* loss_f32,
+                                 double* coef, sn_stream_t stream) {
     if (int rc = check_common("sn_loss_forward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
     if (!bin_w || !parts_ws || !stats || !loss || !coef)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_forward: null pointer");
@@ -545,8 +551,18 @@ extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt,
     if (int rc = sn::check_launch("sn_loss_forward(stats)")) return rc;
     LossCfg cfg{terms, mse_weight, tversky_alpha, tversky_beta, focal_gamma, tversky_smooth, dice_smooth};
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kCombineThreads), 0, s, parts_ws, B, nparts, (long)n_per, H, bin_w,
-                       cfg, stats, loss, coef);
+                       cfg, stats, loss, coef, loss_f32);
     return sn::check_launch("sn_loss_forward(combine)");
+}
+
+extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                               const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                               double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                               double dice_smooth, double* parts_ws, double* stats, double* loss, double* coef,
+                               sn_stream_t stream) {
+    return sn_loss_forward_m(pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, bin_w, H, terms, mse_weight, tversky_alpha,
+                             tversky_beta, focal_gamma, tversky_smooth, dice_smooth, parts_ws, stats, loss, nullptr, coef,
+                             stream);
 }
 
 extern "C" int sn_param_penalty(const float* P, const int8_t* mask, int N, float weight, int with_sum, float* value,
@@ -559,10 +575,14 @@ extern "C" int sn_param_penalty(const float* P, const int8_t* mask, int N, float
     return sn::check_launch("sn_param_penalty");
 }
 
-extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
-                                const float* ranges, int H, const double* coef, const double* upstream,
-                                void* grad_pred, sn_stream_t stream) {
+extern "C" int sn_loss_backward_u(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                  const float* ranges, int H, const double* coef, const void* upstream_v, int up_dtype,
+                                  void* grad_pred, sn_stream_t stream) {
     if (int rc = check_common("sn_loss_backward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
+    if (upstream_v && up_dtype != SN_F64 && up_dtype != SN_F32)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward_u: up_dtype %d (SN_F64 | SN_F32)", up_dtype);
+    const double* upstream = (upstream_v && up_dtype == SN_F64) ? static_cast<const double*>(upstream_v) : nullptr;
+    const float* upstream32 = (upstream_v && up_dtype == SN_F32) ? static_cast<const float*>(upstream_v) : nullptr;
     if (!coef || !grad_pred) return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: null pointer");
     if (n_per % 4 == 0 && ((uintptr_t)grad_pred % (pred_dtype == SN_BF16 ? 8 : 16)))
         return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward: grad_pred must be 16-byte (bf16: 8-byte) aligned");
@@ -574,8 +594,14 @@ extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt
     const long span = span_of(n_per, nparts);
 #define SN_GRAD(PT, GT, BIN)                                                                                      \
     hipLaunchKernelGGL((loss_grad_kernel<PT, GT, BIN>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,   \
-                       (const GT*)gt, (long)n_per, span, ranges, H, coef, upstream, (PT*)grad_pred)
+                       (const GT*)gt, (long)n_per, span, ranges, H, coef, upstream, upstream32, (PT*)grad_pred)
     SN_LOSS_DISPATCH(SN_GRAD);
 #undef SN_GRAD
     return sn::check_launch("sn_loss_backward");
+}
+
+extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                const float* ranges, int H, const double* coef, const double* upstream,
+                                void* grad_pred, sn_stream_t stream) {
+    return sn_loss_backward_u(pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H, coef, upstream, SN_F64, grad_pred, stream);
 }

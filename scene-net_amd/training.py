@@ -65,6 +65,19 @@ def voxelize_and_forward(pipe: ScenePipeline, batch: PointBatch):
     return grids, model(grids.occ, bank_lam=bank_lam if grids.rider_done else None)
 
 
+_SEEDS = {}
+
+
+def backward_seeded(loss: torch.Tensor) -> None:
+    """loss.backward() with the seed gradient taken from a cached one-element tensor: autograd otherwise builds
+    ones_like(loss) with a fill launch at every step (~4 us of GPU time in a replayed graph)."""
+    key = (loss.device, loss.dtype)
+    one = _SEEDS.get(key)
+    if one is None:
+        one = _SEEDS[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(gradient=one)
+
+
 class CapturedTrainingStep:
     """step = zero_grad; grids = pipe.voxelize(batch, want_gt=True); loss = criterion(model(grids.occ), grids.gt_occ,
     cvx coefficients, GENEO parameters); loss.backward(); [all-reduce of the gradients over `group`]; optimizer.step().
@@ -88,7 +101,7 @@ class CapturedTrainingStep:
                 loss = loss_fn(pred, grids)
             else:
                 loss = criterion(pred, grids.gt_occ, model.get_cvx_coefficients(), model.get_geneo_params())
-            loss.backward()
+            backward_seeded(loss)
             return loss
 
         def exchange():

@@ -89,7 +89,7 @@ def test_bce_clamps_like_torch(hip_device):
     gt = torch.tensor([[0.0, 1.0, 1.0, 0.0, 1.0, 0.0]], dtype=torch.float64)
     ranges = torch.zeros(1, dtype=torch.float32, device=hip_device)
     bin_w = torch.ones(1, dtype=torch.float32, device=hip_device)
-    loss, _, coef = _hip.loss_forward(pred.to(hip_device), gt.to(hip_device), ranges, bin_w, _hip.SN_LOSS_WBCE)
+    loss, _, coef, _ = _hip.loss_forward(pred.to(hip_device), gt.to(hip_device), ranges, bin_w, _hip.SN_LOSS_WBCE)
     po = pred.clone().requires_grad_(True)
     ref = torch.nn.functional.binary_cross_entropy(po, gt)
     ref.backward()
@@ -156,8 +156,9 @@ def test_full_size_properties(hip_device):
     bin_w = torch.linspace(0.1, 1.0, 10).to(hip_device).contiguous()
     terms = _hip.SN_LOSS_WMSE | _hip.SN_LOSS_FOCAL_TVERSKY | _hip.SN_LOSS_DICE | _hip.SN_LOSS_WBCE
     pred = pred.clamp(0.05, 0.95)   # keeps the BCE term's higher derivatives tame for the difference quotient
-    l1, stats, coef = _hip.loss_forward(pred, gt, ranges, bin_w, terms, focal_gamma=1.5)
-    l2, stats2, coef2 = _hip.loss_forward(pred, gt, ranges, bin_w, terms, focal_gamma=1.5)
+    l1, stats, coef, l1f = _hip.loss_forward(pred, gt, ranges, bin_w, terms, focal_gamma=1.5)
+    l2, stats2, coef2, _ = _hip.loss_forward(pred, gt, ranges, bin_w, terms, focal_gamma=1.5)
+    assert torch.equal(l1f, l1.float())   # the float32 mirror: the same five numbers rounded once
     assert torch.equal(l1, l2) and torch.equal(stats, stats2) and torch.equal(coef, coef2)
     assert stats[:, :10].sum().item() == B * n
     assert stats[:, 0].sum().item() == (~gt).sum().item() and stats[:, 9].sum().item() == gt.sum().item()
@@ -166,6 +167,7 @@ def test_full_size_properties(hip_device):
     up = torch.tensor([2.5], dtype=torch.float64, device=hip_device)
     g2 = _hip.loss_backward(pred, gt, ranges, coef, up)
     assert (g2 - 2.5 * g1).abs().max().item() <= 1e-12 * g1.abs().max().item()
+    assert torch.equal(_hip.loss_backward(pred, gt, ranges, coef, up.float()), g2)   # a float32 upstream is read as it is
     d = g1 / g1.abs().max() + 0.1 * torch.randn_like(pred)
     h = 1e-5
     lp = _hip.loss_forward(pred + h * d, gt, ranges, bin_w, terms, focal_gamma=1.5)[0][0].item()

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scene_net_amd as sna  # noqa: E402
 from scene_net_amd import _hip  # noqa: E402
 from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile  # noqa: E402
-from scene_net_amd.training import voxelize_and_forward  # noqa: E402
+from scene_net_amd.training import backward_seeded, voxelize_and_forward  # noqa: E402
 
 
 def timed(fn, iters, warm=2, spin_ms=150.0):
@@ -67,7 +67,7 @@ def main():
     terms = _hip.SN_LOSS_WMSE | _hip.SN_LOSS_FOCAL_TVERSKY
 
     t_fwd = timed(lambda: _hip.loss_forward(pred, gt, ranges, bin_w, terms), args.iters)
-    _, _, coef = _hip.loss_forward(pred, gt, ranges, bin_w, terms)
+    _, _, coef, _ = _hip.loss_forward(pred, gt, ranges, bin_w, terms)
     t_bwd = timed(lambda: _hip.loss_backward(pred, gt, ranges, coef), args.iters)
     fwd_bytes = n * (pred.element_size() + gt.element_size())
     bwd_bytes = fwd_bytes + n * pred.element_size()
@@ -80,7 +80,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         g, out = voxelize_and_forward(pipe, batch)   # (the forward's opener rides in the voxelisation's first launch)
         loss = crit(out, g.gt_occ, model.get_cvx_coefficients(), model.get_geneo_params())
-        loss.backward()
+        backward_seeded(loss)   # (loss.backward() with a cached seed: no ones_like launch)
         opt.step()
         return loss
 
