@@ -190,6 +190,15 @@ int sn_conv_i8_spin_timeouts(unsigned long long* count);
  * the combination, ~1e-6 on the output. */
 int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y,
                   int G, int kz, int kx, int ky, void* out, int out_dtype, sn_stream_t stream);
+/* sn_conv_fused with the guard's verdict in a caller-owned device word (0: served by the combined int8 kernel, 1: its
+ * quantisation bound exceeded the tolerance and the gated fp32 launches behind took over) -- the verdict depends on the
+ * weights, the coefficients and the tolerance only, so a caller that has READ 0 for these very parameters may pass
+ * assume_served = 1 and the (then empty) gated launches are left out, as sn_conv_bank_prepared_served does for the
+ * contraction.  bf16 output runs unguarded (the verdict is then not written). */
+int sn_conv_fused_v(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
+                    int kz, int kx, int ky, void* out, int out_dtype, int32_t* verdict, int assume_served,
+                    sn_stream_t stream);
+
 /* 1 when sn_conv_fused serves a [B,1,Z,X,Y] SN_OCC8 grid with a [kz,kx,ky] kernel (Y % 4, the ky window, the tables and
  * the halo within 160 KiB of LDS), else 0: the caller's dispatch predicate, from the same plan the launch uses. */
 int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int kx, int ky);

@@ -76,6 +76,7 @@ SYMBOLS = {
                         + [_P, _P, _P, _P, _P]),
     "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
     "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
+    "sn_conv_fused_v": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "sn_loss_forward_m": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
                           + [_P, _P, _P, _P, _P, _P]),
     "sn_loss_backward_u": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _I, _P, _P]),
@@ -301,6 +302,8 @@ class PreparedVerdict:
         self._event = None
 
     def served(self, key) -> bool:
+        if torch.cuda.is_current_stream_capturing():
+            return False   # a captured graph outlives these parameters: it keeps the fallback launch
         if key != self._key:
             self._key, self._state = key, 0
             return False
@@ -309,9 +312,12 @@ class PreparedVerdict:
         return self._state == 2
 
     def note(self, prep: torch.Tensor, key) -> None:
+        self.note_words(prep_verdicts(prep), key)
+
+    def note_words(self, words: torch.Tensor, key) -> None:
+        """`words`: int32 device tensor of verdict words (all 0 = served) written by the launch just enqueued"""
         if key != self._key or self._state != 0 or torch.cuda.is_current_stream_capturing():
             return
-        words = prep_verdicts(prep)
         if self._host is None or self._host.numel() != words.numel():
             self._host = torch.empty(words.numel(), dtype=torch.int32, pin_memory=True)
         self._host.copy_(words, non_blocking=True)
@@ -385,14 +391,23 @@ def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
 
 @_on_tensor_device
 def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
-               out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """relu(tanh(conv3d(x, sum_g lambda_g K_g))) [B,1,Z,X,Y] (sn_conv_fused): the forward output through linearity."""
+               out_dtype: torch.dtype = torch.float32, verdict: Optional[torch.Tensor] = None,
+               assume_served: bool = False) -> torch.Tensor:
+    """relu(tanh(conv3d(x, sum_g lambda_g K_g))) [B,1,Z,X,Y] (sn_conv_fused): the forward output through linearity.
+    verdict: a caller-owned int32 [1] device tensor that receives the guard's verdict (sn_conv_fused_v); assume_served:
+    the caller has read it as 0 for these weights / coefficients / tolerance -- the gated fp32 launches are left out."""
     B, _, Z, X, Y = x.shape
     G, kz, kx, ky = bank.shape
     out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device)
-    rc = load().sn_conv_fused(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
-                              _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky, _ptr(out),
-                              _DT_OUT[out_dtype], _stream())
+    if verdict is None:
+        rc = load().sn_conv_fused(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                                  _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky, _ptr(out),
+                                  _DT_OUT[out_dtype], _stream())
+    else:
+        rc = load().sn_conv_fused_v(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                                    _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky, _ptr(out),
+                                    _DT_OUT[out_dtype], _ptr(verdict, torch.int32, "verdict"), int(bool(assume_served)),
+                                    _stream())
     _check(rc, "sn_conv_fused")
     return out
 

@@ -24,7 +24,7 @@ int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* 
                     int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
                     sn_stream_t stream);   // conv.hip
 int conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
-                   int kx, int ky, void* out, int out_dtype, hipStream_t stream);
+                   int kx, int ky, void* out, int out_dtype, hipStream_t stream, int32_t* verdict = nullptr, bool assume_served = false);
 }
 
 namespace {
@@ -568,7 +568,8 @@ extern "C" int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int k
 
 // returns SN_ERR_UNSUPPORTED (without touching the error text) when the shape is outside this kernel
 int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
-                       int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream) {
+                       int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream, int32_t* verdict,
+                       bool assume_served) {
     if (((uintptr_t)x % 4) || ((uintptr_t)out % (out_dtype == SN_BF16 ? 8 : 16))) return SN_ERR_UNSUPPORTED;
     LinShape s;
     size_t lds = 0;
@@ -582,7 +583,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     if (out_dtype == SN_BF16) s.tol = 0.0f;   // bf16 storage rounds at 2^-9: the 24-bit fixed point is not what limits it
     s.route = nullptr;
     if (s.tol > 0.0f) {
-        s.route = sn::device_flag_slot(stream);
+        s.route = verdict ? verdict : sn::device_flag_slot(stream);   // (a caller-owned word can be read back: sn_conv_fused_v)
         if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
     }
 #define SN_LAUNCH_LIN(OT)                                                                                         \
@@ -598,7 +599,9 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     else return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused: out_dtype %d", out_dtype);
 #undef SN_LAUNCH_LIN
     if (int rc = sn::check_launch("sn_conv_fused")) return rc;
-    if (s.route) {   // the 16-kernel contraction on the fp32 matrix pipe, enqueued behind: runs only if the guard sent it there
+    // assume_served: the caller has READ this verdict (0) for these very weights, coefficients and tolerance -- it depends on
+    // nothing else -- so the gated launches would do nothing and are left out (the kernel still writes its verdict)
+    if (s.route && !assume_served) {   // the 16-kernel contraction on the fp32 matrix pipe, enqueued behind: runs only if the guard sent it there
         sn::GateScope guard(s.route, 1);
         const size_t ntaps = (size_t)kz * kx * ky;
         for (int g0 = 0; g0 < G; g0 += 16) {
@@ -703,6 +706,22 @@ extern "C" int sn_conv_fused(const void* x, int x_dtype, const float* bank, cons
                                       sn::as_stream(stream));
     if (rc == SN_ERR_UNSUPPORTED)
         return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused: shape outside the kernel (Y %% 4, ky window, LDS); use "
+                                            "sn_conv_bank");
+    return rc;
+}
+
+extern "C" int sn_conv_fused_v(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X,
+                               int Y, int G, int kz, int kx, int ky, void* out, int out_dtype, int32_t* verdict,
+                               int assume_served, sn_stream_t stream) {
+    if (!x || !bank || !lambdas || !out || !verdict) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_v: null pointer");
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_v: non-positive extent");
+    if (x_dtype != SN_OCC8)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused_v: binary occupancy (SN_OCC8) input only; use sn_conv_bank");
+    const int rc = sn::conv_fused_lin((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, out, out_dtype,
+                                      sn::as_stream(stream), verdict, assume_served != 0);
+    if (rc == SN_ERR_UNSUPPORTED)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused_v: shape outside the kernel (Y %% 4, ky window, LDS); use "
                                             "sn_conv_bank");
     return rc;
 }

@@ -129,7 +129,7 @@ class ScenePipeline:
                     bank, prep = model.compute_bank_prepared(dev)
                 x = grids.occ
                 if model.fused_forward and _hip.conv_fused_supported(x, model.kernel_size_of_bank()):
-                    out = _hip.conv_fused(x, bank, lam, out_dtype=model.activation_dtype or torch.float32)
+                    out = model.fused_served(x, bank, lam, model.activation_dtype or torch.float32)
                 else:
                     out = model.contract_prepared(x, bank, lam, prep)[1]
                 return self._finish(out, grids, batch, want_gt)
@@ -138,7 +138,7 @@ class ScenePipeline:
             join()
             x = grids.occ
             if model.fused_forward and _hip.conv_fused_supported(x, model.kernel_size_of_bank()):
-                out = _hip.conv_fused(x, bank, lam, out_dtype=model.activation_dtype or torch.float32)
+                out = model.fused_served(x, bank, lam, model.activation_dtype or torch.float32)
             else:
                 out = (model.contract_prepared(x, bank, lam, prep)[1] if prep is not None and x.dtype == torch.bool
                        else _hip.conv_bank(x, bank, lam, want_act=False, want_out=True)[1])

@@ -326,6 +326,26 @@ class SceneNet(nn.Module):
             verdict.note(prep, key)
         return res
 
+    def fused_served(self, x: torch.Tensor, bank: torch.Tensor, lam: torch.Tensor, out_dtype: torch.dtype):
+        """sn_conv_fused on (bank, lam) of THIS model's current parameters: the guard's verdict is learnt as in
+        contract_prepared (asynchronously, keyed on the parameter versions and the tolerance), and once it has read
+        "served" the gated fp32 launches behind the combined kernel are left out."""
+        if out_dtype == torch.bfloat16:   # (runs unguarded: nothing to learn)
+            return _hip.conv_fused(x, bank, lam, out_dtype=out_dtype)
+        key = (x.device, _hip.get_option("conv_i8_tolerance_ppb"),
+               self._pack_cache[0] if self._pack_cache is not None else None,
+               self._lambda_cache[0] if self._lambda_cache is not None else None)
+        state = self.__dict__.get("_fused_verdict")
+        if state is None or state[1].device != x.device:
+            state = (_hip.PreparedVerdict(), torch.zeros(1, dtype=torch.int32, device=x.device))
+            self.__dict__["_fused_verdict"] = state
+        verdict, word = state
+        served = verdict.served(key)
+        out = _hip.conv_fused(x, bank, lam, out_dtype=out_dtype, verdict=word, assume_served=served)
+        if not served:
+            verdict.note_words(word, key)
+        return out
+
     def serves_prepared(self, x: torch.Tensor) -> bool:
         """binary occupancy and a 9 x 9 x 9 bank: the z-walk kernel behind sn_conv_bank_prepared"""
         return x.dtype == torch.bool and x.is_cuda and self.kernel_size_of_bank() == (9, 9, 9)
@@ -413,7 +433,7 @@ class SceneNet(nn.Module):
             out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
             if self.fused_forward and not return_bank_activations:
                 if _hip.conv_fused_supported(x, ks):
-                    return _hip.conv_fused(x.contiguous(), bank, lam, out_dtype=self.activation_dtype or out_dtype)
+                    return self.fused_served(x.contiguous(), bank, lam, self.activation_dtype or out_dtype)
                 if x.dtype in (torch.float32, torch.float64):
                     # what the reference feeds is f64 {0., 1.} (ToFullDense): a device-side check routes such grids
                     # to the int8 kernels and anything else to the fp32 contraction, without a host sync

@@ -343,3 +343,40 @@ def test_verdict_is_learnt_without_a_sync_and_the_fallback_launch_left_out(hip_d
                                            torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert rc == 0 and _hip.prep_verdicts(prep).cpu().tolist() == [1] and bool((canary == -7.0).all())
+
+
+def test_fused_forward_learns_its_verdict_and_drops_the_gated_launches(hip_device):
+    """SceneNet.fused_served (the module's default no-grad forward on binary occupancy): the guard's verdict of sn_conv_fused_v
+    lands in a caller-owned word, is learnt without a synchronisation, and from then on the gated fp32 launches are left
+    out -- same bits before and after; a parameter change starts over; a tolerance the bank cannot meet is read as "not
+    served" and keeps the fallback (whose result then differs from the unguarded kernel's)."""
+    model = _bench_model(hip_device)
+    model.fused_forward = True
+    x = (torch.rand(2, 1, 64, 64, 64, device=hip_device) < 0.05)
+    with torch.no_grad():
+        first = model(x)
+        torch.cuda.synchronize()
+        verdict, word = model._fused_verdict
+        assert int(word.item()) == 0
+        again = model(x)            # picks the read-back up: served
+        assert verdict._state == 2
+        served = model(x)
+        assert torch.equal(first, again) and torch.equal(first, served)
+        # a changed coefficient: a new key, the fallback is back until the verdict has been read again
+        name = next(n for n in model.lambdas_dict if n != model.last_lambda)
+        model.lambdas_dict[name].mul_(1.5)   # (an in-place op under no_grad: bumps the version the caches key on)
+        changed = model(x)
+        assert verdict._state in (0, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(model(x), changed)
+        # an impossible tolerance: verdict 1, never "served", the fp32 contraction's result
+        _hip.set_option("conv_i8_tolerance_ppb", 1)
+        try:
+            strict = model(x)
+            torch.cuda.synchronize()
+            assert int(word.item()) == 1
+            assert torch.equal(model(x), strict) and verdict._state == 3
+            bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+            assert torch.equal(strict, _hip.conv_bank(x.view(torch.uint8), bank, lam, want_act=False, want_out=True)[1])
+        finally:
+            _hip.set_option("conv_i8_tolerance_ppb", 90000)
