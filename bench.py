@@ -369,9 +369,11 @@ def main():
     # on, so: an extra, never `value`.
     fused_info = None
     if not args.no_extras and sna._hip.conv_fused_supported(pipe.voxelize(batch).occ, KERNEL_SIZE):
-        def fused_step():
-            grids = pipe.voxelize(batch)
-            return sna._hip.conv_fused(grids.occ, model.compute_bank(dev), model.effective_lambdas(dev))
+        def fused_step():   # (what ScenePipeline runs for the module's default forward: K2 riding in K1's first launch, the
+            # guard's gated launches left out once its verdict has been read for these parameters)
+            _, _, bank_f, _ = rider_f = model.bank_rider(dev)
+            grids = pipe.voxelize(batch, bank_rider=rider_f)
+            return model.fused_served(grids.occ, bank_f, model.effective_lambdas(dev), torch.float32)
         nf = max(30, args.steps)   # a 0.12 ms step: ten of them are too few to time against the host clock
         out_fused = None
         for _ in range(3):
