@@ -199,7 +199,7 @@ extern "C" int sn_prepare_device(void) {
     return sn::flag_pool_locked(dev) ? SN_OK : sn::fail(SN_ERR_LAUNCH, "sn_prepare_device: cannot allocate the flag pool");
 }
 
-extern "C" int sn_version(void) { return 101; }
+extern "C" int sn_version(void) { return 102; }   // 102: round-3 entries (riders, sn_conv_corr_ws, sn_conv_fused_v, sn_loss_*_m / _u)
 
 extern "C" const char* sn_last_error(void) { return sn::error_buffer(); }
 
