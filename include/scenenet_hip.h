@@ -478,6 +478,21 @@ int sn_loss_forward_m(const void* pred, int pred_dtype, const void* gt, int gt_d
 int sn_loss_backward_u(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
                        const float* ranges, int H, const double* coef, const void* upstream, int up_dtype, void* grad_pred,
                        sn_stream_t stream);
+/* The criterion of a GENEO_Loss family member (dense terms + cvx_loss + positive_regularizer, geneo_loss.py:36-91, 145-161)
+ * in the launches of sn_loss_forward / sn_loss_backward alone: sn_criterion_forward = sn_loss_forward_m with
+ * sn_param_penalty's work opening the combine launch, and total_f32 [1] = (float)loss[0] + pen_value -- the scalar the
+ * criterion returns; sn_criterion_backward = sn_loss_backward_u with pen_out [N] = pen_grad [N] x upstream riding in the
+ * gradient launch.  Same numbers, bit for bit, as the three forward launches + the torch add / multiply they replace. */
+int sn_criterion_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                         const float* ranges, const float* bin_w, int H, int terms, double mse_weight, double tversky_alpha,
+                         double tversky_beta, double focal_gamma, double tversky_smooth, double dice_smooth,
+                         double* parts_ws, double* stats, double* loss, float* loss_f32, double* coef, const float* P,
+                         const int8_t* mask, int N, float weight, int with_sum, float* pen_value, float* pen_grad,
+                         float* total_f32, sn_stream_t stream);
+int sn_criterion_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                          const float* ranges, int H, const double* coef, const void* upstream, int up_dtype,
+                          void* grad_pred, const float* pen_grad, int N, float* pen_out, sn_stream_t stream);
+
 
 
 #ifdef __cplusplus

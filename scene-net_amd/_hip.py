@@ -80,6 +80,9 @@ SYMBOLS = {
     "sn_loss_forward_m": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
                           + [_P, _P, _P, _P, _P, _P]),
     "sn_loss_backward_u": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _I, _P, _P]),
+    "sn_criterion_forward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
+                             + [_P, _P, _P, _P, _P, _P, _P, _I, ctypes.c_float, _I, _P, _P, _P, _P]),
+    "sn_criterion_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
 }
 SN_CONV_PREP_BYTES = 16384
 SN_LOSS_WMSE, SN_LOSS_FOCAL_TVERSKY, SN_LOSS_DICE, SN_LOSS_WBCE = 1, 2, 4, 8
@@ -300,6 +303,10 @@ class PreparedVerdict:
         self._state = 0          # 0 nothing known, 1 read-back in flight, 2 served, 3 not served
         self._host = None
         self._event = None
+
+    def __reduce__(self):
+        # copied / pickled with a module: a fresh object that knows nothing (the event and the pinned buffer stay behind)
+        return (PreparedVerdict, ())
 
     def served(self, key) -> bool:
         if torch.cuda.is_current_stream_capturing():
@@ -820,6 +827,57 @@ def loss_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin
                                   _ptr(loss), _ptr(loss32), _ptr(coef), _stream())
     _check(rc, "sn_loss_forward")
     return loss, stats, coef, loss32
+
+
+@_on_tensor_device
+def criterion_forward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_w: torch.Tensor, terms: int,
+                      P: torch.Tensor, mask: torch.Tensor, weight: float, with_sum: bool, mse_weight: float = 1.0,
+                      tversky_alpha: float = 0.5, tversky_beta: float = 1.0, focal_gamma: float = 1.0,
+                      tversky_smooth: float = 1.0, dice_smooth: float = 1.0):
+    """sn_criterion_forward: the dense terms of loss_forward and the penalties of param_penalty over the packed parameters
+    P in the dense loss's two launches.  Returns (total [1] f32 = float(dense) + penalty, stats, coef, pen_grad [N] f32)."""
+    if pred.shape != gt.shape:
+        raise HipLibraryError(f"pred {tuple(pred.shape)} and gt {tuple(gt.shape)} must have the same shape")
+    B = int(pred.shape[0])
+    n_per = pred.numel() // max(B, 1)
+    H = int(ranges.numel())
+    N = int(P.numel())
+    dev = pred.device
+    ws = torch.empty((B * loss_parts(n_per) * (3 * H + 5),), dtype=torch.float64, device=dev)
+    stats = torch.empty((B, 3 * H + 5), dtype=torch.float64, device=dev)
+    loss = torch.empty((5,), dtype=torch.float64, device=dev)
+    coef = torch.empty((2 * SN_LOSS_MAX_BINS + 3 * B,), dtype=torch.float64, device=dev)
+    f32 = torch.empty((7 + N,), dtype=torch.float32, device=dev)   # loss32 [5] | total [1] | penalty [1] | its gradient [N]
+    base = f32.data_ptr()
+    rc = load().sn_criterion_forward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
+                                     n_per, _ptr(ranges, torch.float32, "ranges"), _ptr(bin_w, torch.float32, "bin_w"),
+                                     H, int(terms), float(mse_weight), float(tversky_alpha), float(tversky_beta),
+                                     float(focal_gamma), float(tversky_smooth), float(dice_smooth), _ptr(ws), _ptr(stats),
+                                     _ptr(loss), base, _ptr(coef), _ptr(P, torch.float32, "P"),
+                                     _ptr(mask, torch.int8, "mask"), N, float(weight), int(bool(with_sum)), base + 24,
+                                     base + 28, base + 20, _stream())
+    _check(rc, "sn_criterion_forward")
+    return f32[5:6], stats, coef, f32[7:]
+
+
+@_on_tensor_device
+def criterion_backward(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, coef: torch.Tensor,
+                       upstream: torch.Tensor, pen_grad: torch.Tensor):
+    """sn_criterion_backward: (dL/dpred, penalty gradient x upstream [N] f32) in the gradient pass's one launch."""
+    B = int(pred.shape[0])
+    n_per = pred.numel() // max(B, 1)
+    grad = torch.empty_like(pred)
+    N = int(pen_grad.numel())
+    pen_out = torch.empty((N,), dtype=torch.float32, device=pred.device)
+    if upstream.dtype not in (torch.float64, torch.float32):
+        upstream = upstream.to(torch.float64)
+    rc = load().sn_criterion_backward(_ptr(pred, None, "pred"), _DT[pred.dtype], _ptr(gt, None, "gt"), _DT[gt.dtype], B,
+                                      n_per, _ptr(ranges, torch.float32, "ranges"), int(ranges.numel()),
+                                      _ptr(coef, torch.float64, "coef"), _ptr(upstream, None, "upstream"),
+                                      _DT[upstream.dtype], _ptr(grad), _ptr(pen_grad, torch.float32, "pen_grad"), N,
+                                      _ptr(pen_out), _stream())
+    _check(rc, "sn_criterion_backward")
+    return grad, pen_out
 
 
 @_on_tensor_device

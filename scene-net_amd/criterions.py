@@ -67,6 +67,31 @@ def _dense_loss(pred: torch.Tensor, gt: torch.Tensor, ranges: torch.Tensor, bin_
     return loss
 
 
+class _CriterionFn(torch.autograd.Function):
+    """dense terms + penalties over the packed parameter vector as ONE differentiable op in the dense loss's launches
+    (sn_criterion_forward / sn_criterion_backward): the same numbers, bit for bit, as _DenseLossFn + _PenaltyFn + the float32
+    add between them and the multiply in the penalty's backward -- which a replayed training step paid ~4 us of GPU time each
+    for.  float32 / bf16 predictions (the total is a float32 scalar)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, P, ranges, bin_w, terms, cfg, mask, weight, with_sum):
+        pred_c, gt_c = pred.contiguous(), gt.contiguous()
+        total, stats, coef, pen_grad = _hip.criterion_forward(pred_c, gt_c, ranges, bin_w, terms, P.detach().contiguous(),
+                                                              mask, weight, with_sum, **cfg)
+        ctx.save_for_backward(pred_c, gt_c, ranges, coef, pen_grad)
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return total.reshape(()), stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        if g_loss is None:
+            return (None,) * 10
+        pred, gt, ranges, coef, pen_grad = ctx.saved_tensors
+        dpred, dP = _hip.criterion_backward(pred, gt, ranges, coef, g_loss.detach().reshape(1), pen_grad)
+        return dpred, None, dP, None, None, None, None, None, None, None
+
+
 class _PenaltyFn(torch.autograd.Function):
     """geneo_loss.py:36-70 over the packed parameter vector (sn_param_penalty): value and gradient in one launch."""
 
@@ -361,6 +386,15 @@ class GENEO_Loss(WeightedMSE):
 
     def forward(self, y_pred, y_gt, cvx_coeffs, geneo_params):
         terms, cfg = self._terms()
+        Pc, live = _live_pack(cvx_coeffs)
+        Pp, _ = _live_pack(geneo_params)
+        if (Pc is not None and Pp is Pc and len(cvx_coeffs) and len(geneo_params) and y_pred.is_cuda
+                and y_pred.dtype in (torch.float32, torch.bfloat16) and y_pred.dim() >= 2 and y_pred.shape == y_gt.shape):
+            # one differentiable op in the dense loss's own launches (the common training step)
+            ranges, bin_w = self._device_tables(y_pred.device)
+            loss, _ = _CriterionFn.apply(y_pred, y_gt, Pc, ranges, bin_w, terms, dict(mse_weight=self.mse_weight, **cfg),
+                                         live.mask_all, self.cvx_w, True)
+            return loss
         dense_criterion = self._dense(y_pred, y_gt, terms, **cfg)
         return dense_criterion + self._penalties(cvx_coeffs, geneo_params)
 

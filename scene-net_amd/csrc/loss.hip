@@ -233,6 +233,74 @@ __global__ __launch_bounds__(kThreads) void loss_stats_kernel(const PT* __restri
     }
 }
 
+// ---------------------------------------------------------------- penalties over the ~50 scalars
+// geneo_loss.py:36-70: value = w * ( sum_{mask>=1} relu(-v) + relu(-(1 - sum_{mask==2} v)) ) and its gradient.  fp32 sums in
+// a fixed order (strided partials, then a tree).  A device function: its own launch (param_penalty_kernel) or the opening of
+// the criterion's combine launch (sn_criterion_forward).  Called by every thread of the workgroup (barriers inside); the
+// first 256 threads work; pl: 2 N floats of LDS.
+struct PenaltyArgs {
+    const float* P;
+    const int8_t* mask;
+    int N;
+    float w;
+    int with_sum;
+    float* value;     // [1]
+    float* grad;      // [N]
+    float* total32;   // [1]: (float)(dense loss) + value -- the criterion's scalar
+};
+
+__device__ void param_penalty_body(const float* __restrict__ P, const int8_t* __restrict__ mask, int N, float w, int with_sum,
+                                   float* __restrict__ value, float* __restrict__ grad, float* pl) {
+    int* ml = reinterpret_cast<int*>(pl + N);
+    __shared__ int last_neg_s;
+    __shared__ float part_pen[256], part_sum[256];
+    const int tid = threadIdx.x;
+    if (tid < 256)
+        for (int i = tid; i < N; i += 256) pl[i] = P[i], ml[i] = mask[i];
+    __syncthreads();
+    // per-thread strided partial sums, then thread 0 adds the 256 partials in order (deterministic)
+    if (tid < 256) {
+        float pen = 0.f, free_sum = 0.f;
+        for (int i = tid; i < N; i += 256) {
+            if (ml[i] >= 1) pen += fmaxf(-pl[i], 0.f);
+            if (ml[i] == 2) free_sum += pl[i];
+        }
+        part_pen[tid] = pen;
+        part_sum[tid] = free_sum;
+    }
+    __syncthreads();
+    if (tid < 64) {                // 64 lanes x 4 partials, xor-tree: fixed order
+        float pen = 0.f, free_sum = 0.f;
+        for (int k = 0; k < 4; ++k) pen += part_pen[tid * 4 + k], free_sum += part_sum[tid * 4 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pen += __shfl_xor(pen, o, 64), free_sum += __shfl_xor(free_sum, o, 64);
+        if (tid == 0) {
+            const float last = 1.f - free_sum; // the frozen coefficient, 1 - sum(others)
+            const int last_neg = with_sum && (last < 0.f);
+            if (last_neg) pen += -last;
+            last_neg_s = last_neg;
+            value[0] = w * pen;
+        }
+    }
+    __syncthreads();
+    const bool last_neg = last_neg_s != 0;
+    if (tid < 256)
+        for (int i = tid; i < N; i += 256) {
+            float g = 0.f;
+            if (ml[i] >= 1 && pl[i] < 0.f) g -= 1.f;  // d relu(-v)/dv
+            if (ml[i] == 2 && last_neg) g += 1.f;     // d relu(-(1 - sum))/dv
+            grad[i] = w * g;
+        }
+}
+
+__global__ __launch_bounds__(256) void param_penalty_kernel(const float* __restrict__ P,
+                                                            const int8_t* __restrict__ mask, int N, float w,
+                                                            int with_sum, float* __restrict__ value,
+                                                            float* __restrict__ grad) {
+    extern __shared__ float pl[];          // [N] values, then [N] masks
+    param_penalty_body(P, mask, N, w, with_sum, value, grad, pl);
+}
+
 // ---------------------------------------------------------------- one block: parts -> stats -> loss + coefficients
 struct LossCfg {
     int terms;
@@ -244,7 +312,11 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
                                                                 long n_per, int H, const float* __restrict__ bin_w,
                                                                 LossCfg cfg, double* __restrict__ stats,
                                                                 double* __restrict__ loss, double* __restrict__ coef,
-                                                                float* __restrict__ loss32) {
+                                                                float* __restrict__ loss32, PenaltyArgs pen) {
+    if (pen.P) {   // (the criterion's penalties open the launch: sn_criterion_forward)
+        extern __shared__ float pen_lds[];
+        param_penalty_body(pen.P, pen.mask, pen.N, pen.w, pen.with_sum, pen.value, pen.grad, pen_lds);
+    }
     __shared__ double tot[3 * kMaxBins + 5];
     __shared__ double dice_part[kCombineThreads];
     const int nstat = 3 * H + 5;
@@ -347,6 +419,8 @@ __global__ __launch_bounds__(kCombineThreads) void loss_combine_kernel(const dou
 #pragma unroll
             for (int k = 0; k < 5; ++k) loss32[k] = (float)loss[k];
         }
+        // (thread 0 wrote pen.value itself: the float32 sum GENEO_Loss.forward formed with a launch of its own)
+        if (pen.P) pen.total32[0] = (float)loss[0] + pen.value[0];
     }
     __syncthreads();
     if (threadIdx.x < kMaxBins) {
@@ -374,7 +448,15 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
                                                              int H, const double* __restrict__ coef,
                                                              const double* __restrict__ upstream,
                                                              const float* __restrict__ upstream32,
-                                                             PT* __restrict__ grad) {
+                                                             PT* __restrict__ grad, int B, const float* __restrict__ pen_grad,
+                                                             int pen_n, float* __restrict__ pen_out) {
+    if ((int)blockIdx.y >= B) {   // the rider row (sn_criterion_backward): the penalties' gradient times the upstream scalar
+        if (blockIdx.x == 0) {
+            const float upf = upstream ? (float)*upstream : (upstream32 ? *upstream32 : 1.0f);
+            for (int i = threadIdx.x; i < pen_n; i += kThreads) pen_out[i] = pen_grad[i] * upf;
+        }
+        return;
+    }
     using C = typename ComputeOf<PT>::type;  // gradient arithmetic in pred's dtype (bf16 storage: fp32)
     __shared__ C ck[kMaxBins], ek[kMaxBins];
     __shared__ int lut[256];
@@ -438,53 +520,6 @@ __global__ __launch_bounds__(kThreads) void loss_grad_kernel(const PT* __restric
     }
 }
 
-// ---------------------------------------------------------------- penalties over the ~50 scalars
-// geneo_loss.py:36-70 in one launch: value = w * ( sum_{mask>=1} relu(-v) + relu(-(1 - sum_{mask==2} v)) ) and its
-// gradient.  fp32 sums in a fixed order (strided partials, then a tree).
-__global__ __launch_bounds__(256) void param_penalty_kernel(const float* __restrict__ P,
-                                                            const int8_t* __restrict__ mask, int N, float w,
-                                                            int with_sum, float* __restrict__ value,
-                                                            float* __restrict__ grad) {
-    extern __shared__ float pl[];          // [N] values, then [N] masks
-    int* ml = reinterpret_cast<int*>(pl + N);
-    __shared__ int last_neg_s;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) pl[i] = P[i], ml[i] = mask[i];
-    __syncthreads();
-    // per-thread strided partial sums, then thread 0 adds the 256 partials in order (deterministic)
-    __shared__ float part_pen[256], part_sum[256];
-    {
-        float pen = 0.f, free_sum = 0.f;
-        for (int i = threadIdx.x; i < N; i += blockDim.x) {
-            if (ml[i] >= 1) pen += fmaxf(-pl[i], 0.f);
-            if (ml[i] == 2) free_sum += pl[i];
-        }
-        part_pen[threadIdx.x] = pen;
-        part_sum[threadIdx.x] = free_sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                // 64 lanes x 4 partials, xor-tree: fixed order
-        float pen = 0.f, free_sum = 0.f;
-        for (int k = 0; k < 4; ++k) pen += part_pen[threadIdx.x * 4 + k], free_sum += part_sum[threadIdx.x * 4 + k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) pen += __shfl_xor(pen, o, 64), free_sum += __shfl_xor(free_sum, o, 64);
-        if (threadIdx.x == 0) {
-            const float last = 1.f - free_sum; // the frozen coefficient, 1 - sum(others)
-            const int last_neg = with_sum && (last < 0.f);
-            if (last_neg) pen += -last;
-            last_neg_s = last_neg;
-            value[0] = w * pen;
-        }
-    }
-    __syncthreads();
-    const bool last_neg = last_neg_s != 0;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        float g = 0.f;
-        if (ml[i] >= 1 && pl[i] < 0.f) g -= 1.f;  // d relu(-v)/dv
-        if (ml[i] == 2 && last_neg) g += 1.f;     // d relu(-(1 - sum))/dv
-        grad[i] = w * g;
-    }
-}
-
 int check_common(const char* fn, const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
                  const float* ranges, int H) {
     if (!pred || !gt || !ranges) return sn::fail(SN_ERR_INVALID_ARG, "%s: null pointer", fn);
@@ -529,11 +564,11 @@ long span_of(int64_t n_per, int nparts) {
         }                                                                                                         \
     } while (0)
 
-extern "C" int sn_loss_forward_m(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
-                                 const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
-                                 double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
-                                 double dice_smooth, double* parts_ws, double* stats, double* loss, float* loss_f32,
-                                 double* coef, sn_stream_t stream) {
+static int loss_forward_impl(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                             const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                             double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                             double dice_smooth, double* parts_ws, double* stats, double* loss, float* loss_f32,
+                             double* coef, const PenaltyArgs& pen, sn_stream_t stream) {
     if (int rc = check_common("sn_loss_forward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
     if (!bin_w || !parts_ws || !stats || !loss || !coef)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_forward: null pointer");
@@ -550,9 +585,37 @@ extern "C" int sn_loss_forward_m(const void* pred, int pred_dtype, const void* g
 #undef SN_STATS
     if (int rc = sn::check_launch("sn_loss_forward(stats)")) return rc;
     LossCfg cfg{terms, mse_weight, tversky_alpha, tversky_beta, focal_gamma, tversky_smooth, dice_smooth};
-    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kCombineThreads), 0, s, parts_ws, B, nparts, (long)n_per, H, bin_w,
-                       cfg, stats, loss, coef, loss_f32);
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kCombineThreads), pen.P ? (size_t)pen.N * 8 : 0, s, parts_ws, B,
+                       nparts, (long)n_per, H, bin_w, cfg, stats, loss, coef, loss_f32, pen);
     return sn::check_launch("sn_loss_forward(combine)");
+}
+
+extern "C" int sn_loss_forward_m(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                 const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                                 double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                                 double dice_smooth, double* parts_ws, double* stats, double* loss, float* loss_f32,
+                                 double* coef, sn_stream_t stream) {
+    return loss_forward_impl(pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, bin_w, H, terms, mse_weight, tversky_alpha,
+                             tversky_beta, focal_gamma, tversky_smooth, dice_smooth, parts_ws, stats, loss, loss_f32, coef,
+                             PenaltyArgs{nullptr, nullptr, 0, 0.f, 0, nullptr, nullptr, nullptr}, stream);
+}
+
+// The whole criterion of a GENEO_Loss family member in the two launches of sn_loss_forward: the penalties over the packed
+// parameters (sn_param_penalty's arithmetic) open the combine launch, which also writes total_f32 = (float)loss[0] + penalty
+// -- the float32 sum the reference forms at geneo_loss.py:86-91 / 155-161 -- so a replayed training step has no penalty
+// launch and no one-element add.
+extern "C" int sn_criterion_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                    const float* ranges, const float* bin_w, int H, int terms, double mse_weight,
+                                    double tversky_alpha, double tversky_beta, double focal_gamma, double tversky_smooth,
+                                    double dice_smooth, double* parts_ws, double* stats, double* loss, float* loss_f32,
+                                    double* coef, const float* P, const int8_t* mask, int N, float weight, int with_sum,
+                                    float* pen_value, float* pen_grad, float* total_f32, sn_stream_t stream) {
+    if (!P || !mask || !pen_value || !pen_grad || !total_f32)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_criterion_forward: null pointer");
+    if (N <= 0 || N > 8192) return sn::fail(SN_ERR_UNSUPPORTED, "sn_criterion_forward: 1 <= N <= 8192");
+    return loss_forward_impl(pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, bin_w, H, terms, mse_weight, tversky_alpha,
+                             tversky_beta, focal_gamma, tversky_smooth, dice_smooth, parts_ws, stats, loss, loss_f32, coef,
+                             PenaltyArgs{P, mask, N, weight, with_sum, pen_value, pen_grad, total_f32}, stream);
 }
 
 extern "C" int sn_loss_forward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
@@ -575,9 +638,9 @@ extern "C" int sn_param_penalty(const float* P, const int8_t* mask, int N, float
     return sn::check_launch("sn_param_penalty");
 }
 
-extern "C" int sn_loss_backward_u(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
-                                  const float* ranges, int H, const double* coef, const void* upstream_v, int up_dtype,
-                                  void* grad_pred, sn_stream_t stream) {
+static int loss_backward_impl(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                              const float* ranges, int H, const double* coef, const void* upstream_v, int up_dtype,
+                              void* grad_pred, const float* pen_grad, int pen_n, float* pen_out, sn_stream_t stream) {
     if (int rc = check_common("sn_loss_backward", pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H)) return rc;
     if (upstream_v && up_dtype != SN_F64 && up_dtype != SN_F32)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_loss_backward_u: up_dtype %d (SN_F64 | SN_F32)", up_dtype);
@@ -593,11 +656,29 @@ extern "C" int sn_loss_backward_u(const void* pred, int pred_dtype, const void* 
     const int nparts = n_per <= 8192 ? 1 : (n_per >= 8192L * 512 ? 512 : (int)((n_per + 8191) / 8192));
     const long span = span_of(n_per, nparts);
 #define SN_GRAD(PT, GT, BIN)                                                                                      \
-    hipLaunchKernelGGL((loss_grad_kernel<PT, GT, BIN>), dim3(nparts, B), dim3(kThreads), 0, s, (const PT*)pred,   \
-                       (const GT*)gt, (long)n_per, span, ranges, H, coef, upstream, upstream32, (PT*)grad_pred)
+    hipLaunchKernelGGL((loss_grad_kernel<PT, GT, BIN>), dim3(nparts, B + (pen_grad ? 1 : 0)), dim3(kThreads), 0, s,  \
+                       (const PT*)pred, (const GT*)gt, (long)n_per, span, ranges, H, coef, upstream, upstream32,     \
+                       (PT*)grad_pred, B, pen_grad, pen_n, pen_out)
     SN_LOSS_DISPATCH(SN_GRAD);
 #undef SN_GRAD
     return sn::check_launch("sn_loss_backward");
+}
+
+extern "C" int sn_loss_backward_u(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                  const float* ranges, int H, const double* coef, const void* upstream_v, int up_dtype,
+                                  void* grad_pred, sn_stream_t stream) {
+    return loss_backward_impl(pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H, coef, upstream_v, up_dtype, grad_pred,
+                              nullptr, 0, nullptr, stream);
+}
+
+// sn_loss_backward_u with the penalties' gradient riding in the same launch: pen_out [N] = pen_grad [N] (of
+// sn_criterion_forward) times the upstream scalar -- what autograd did with a multiply launch of its own.
+extern "C" int sn_criterion_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,
+                                     const float* ranges, int H, const double* coef, const void* upstream_v, int up_dtype,
+                                     void* grad_pred, const float* pen_grad, int N, float* pen_out, sn_stream_t stream) {
+    if (!pen_grad || !pen_out || N <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_criterion_backward: null pointer / N");
+    return loss_backward_impl(pred, pred_dtype, gt, gt_dtype, B, n_per, ranges, H, coef, upstream_v, up_dtype, grad_pred,
+                              pen_grad, N, pen_out, stream);
 }
 
 extern "C" int sn_loss_backward(const void* pred, int pred_dtype, const void* gt, int gt_dtype, int B, int64_t n_per,

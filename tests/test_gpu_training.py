@@ -289,3 +289,37 @@ def test_training_step_with_the_opener_riding_in_the_voxelisation(hip_device):
     assert loss_e.item() == losses[-1]
     for (nm, a), (_, b) in zip(model_e.named_parameters(), model_c.named_parameters()):
         assert torch.equal(a.detach(), b.detach()), nm
+
+
+@pytest.mark.parametrize("crit_cls", [sna.GENEO_Tversky_Loss, sna.GENEO_Dice_Loss, sna.GENEO_Loss])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_criterion_equals_its_parts(hip_device, crit_cls, bf16):
+    """GENEO_Loss.forward on a live scene_net_amd model: dense terms + penalties as ONE op in the dense loss's launches
+    (sn_criterion_forward / _backward) == the dense op + the penalty op + torch's add (and, backward, its multiply): the loss
+    and every parameter's gradient bit for bit, for float32 and bf16 predictions, with an upstream factor."""
+    x, y = _data(hip_device, seed=9)
+
+    def run(fused):
+        model = _make(hip_device, seed=13)
+        if bf16:
+            model.activation_dtype = torch.bfloat16
+        with torch.no_grad():   # a negative coefficient and a negative parameter: both penalties are active
+            next(iter(model.lambdas_dict.values())).fill_(-0.3)
+            next(iter(model.geneos.values())).geneo_params["sigma"].fill_(-0.2)
+        crit = crit_cls(targets=y.float(), weighting_scheme_path=None, save_weighting_scheme=False)
+        pred = model(x)
+        cvx, par = model.get_cvx_coefficients(), model.get_geneo_params()
+        if fused:
+            loss = crit(pred, y, cvx, par)
+        else:
+            terms, cfg = crit._terms()
+            loss = crit._dense(pred, y, terms, **cfg) + crit._penalties(cvx, par)
+        (loss * 1.75).backward()
+        return loss.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss_f, grads_f = run(True)
+    loss_p, grads_p = run(False)
+    assert loss_f.dtype == loss_p.dtype == torch.float32 and torch.equal(loss_f, loss_p)
+    assert grads_f.keys() == grads_p.keys() and len(grads_f) > 10
+    for n in grads_f:
+        assert torch.equal(grads_f[n], grads_p[n]), n
