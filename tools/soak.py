@@ -37,18 +37,28 @@ def linear():
         return pipe(batch)
 
 
+def headline():   # bench.py's step: K2 riding in K1's first launch, the z-walk on the prepared blob
+    with torch.no_grad():
+        _, _, bank, prep = rider = model.bank_rider(dev)
+        g = pipe.voxelize(batch, bank_rider=rider)
+        return model.contract_prepared(g.occ, bank, model.effective_lambdas(dev), prep)[1]
+
+
 def run(name, fn):
     ref = fn().clone()
     bad = 0
     for i in range(args.iters):
         out = fn()
-        if i % 250 == 249:
+        if i % 25 == 24:
             bad += int(not torch.equal(out, ref))
+        if i % 500 == 499:
             print(f"{name}: {i + 1} iterations, mismatches so far {bad}", flush=True)
     torch.cuda.synchronize()
     assert bad == 0, name
 
 
+run("headline step (K1 + riders, K3'z)", headline)
+assert _hip.conv_i8_spin_timeouts() == 0
 run("contraction (K3')", contraction)
 run("linear (K3L)", linear)
 _hip.set_option("conv_skip_empty_tiles", 1)
