@@ -340,7 +340,7 @@ bool plan(int B, int Z, int X, int Y, int kz, int kx, int ky, CorrShape* s, size
 // ~2000 instructions per wave and job around a gather of ~400 -- took 102-106 us in two variants, no better than the
 // GEMM form's 96; bound by instruction issue, not by LDS or HBM.)
 constexpr int kSpThreads = 512;
-constexpr int kSpStage = 6;        // delta elements per thread and job (DR Y <= 6 x 512)
+constexpr int kSpStage = 8;        // delta elements per thread and job: 6 single loads (DR Y <= 6 x 512) or 2 quads
 constexpr int kSpListThreads = 256;   // corr_lists_kernel: 8 tile bytes per thread
 
 struct SparseShape {
@@ -352,6 +352,7 @@ struct SparseShape {
     int T, groups;     // taps per plane, voxel groups
     int capP;          // entries per list (TXR Y + padding; a multiple of 8)
     int vec;           // list kernel: a thread's 8 input bytes are one aligned load and lie in one row
+    int vec4;          // gather: the delta tile is staged by four-element loads (Y % 4 == 0, aligned pointers)
     unsigned y_magic;  // e / Y == mulhi(e, y_magic) for every e the kernels form (checked on the host)
     unsigned nxt_magic, b_magic;   // likewise job / nxt and (job / nxt) / B for every job index
     int dbg;           // wrong-result timing switch (SN_CONV_DEBUG builds only: SN_K4S_SKIP): 1 no job does anything, 2 no gather
@@ -491,8 +492,26 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
     const unsigned e_hi = (unsigned)(s.X * s.Y);
     auto issue_delta = [&](const Job& jb, float (&g)[kSpStage], float (&o)[kSpStage]) {
         const size_t dbase = ((size_t)jb.b * s.Z + jb.z) * plane;
+        if (s.vec4) {
+            // four elements per load (rows are whole and Y % 4 == 0: a quad lies in one row, inside or outside the grid as a
+            // whole): two loads per thread and array instead of five ([measured] the scalar form: a latency-bound stream,
+            // 22 of the kernel's 42 us with every job's work switched off; bf16 storage was no faster than fp32)
 #pragma unroll
-        for (int u = 0; u < kSpStage; ++u) {
+            for (int u = 0; u < 2; ++u) {
+                float gq[4] = {0.f, 0.f, 0.f, 0.f}, oq[4] = {1.f, 1.f, 1.f, 1.f};
+                if (4 * u * kSpThreads < nel) {   // (uniform)
+                    const int ge = jb.e_lo + 4 * (u * kSpThreads + tid);
+                    const unsigned at = (unsigned)ge < e_hi ? (unsigned)ge : 0u;
+                    load_quad(gout + dbase + at, gq);
+                    if (out) load_quad(out + dbase + at, oq);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[4 * u + k] = gq[k], o[4 * u + k] = oq[k];
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
             g[u] = 0.f; o[u] = 1.f;
             if (u * kSpThreads < nel) {   // (uniform)
                 const int ge = jb.e_lo + u * kSpThreads + tid;
@@ -529,15 +548,33 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
         if (work) {
             __syncthreads();   // the previous job's gathers are done with the delta tile and the lists
             // ---- delta tile: rows q0 .. q0 + DR - 1 (zero outside the grid), columns ky - 1 - py + y
+            if (s.vec4) {
 #pragma unroll
-            for (int u = 0; u < kSpStage; ++u) {
-                const int e = u * kSpThreads + tid;
-                if (e < nel) {
-                    const int rr = (int)__umulhi((unsigned)e, s.y_magic), y = e - rr * s.Y;
-                    float d = g[u];
-                    if (out) d = (o[u] > 0.f) ? d * (1.f - o[u] * o[u]) : 0.f;
-                    if ((unsigned)(cur.e_lo + e) >= e_hi) d = 0.f;   // a row outside the grid
-                    dl[rr * s.P + (s.ky - 1 - s.py) + y] = d;
+                for (int u = 0; u < 2; ++u) {
+                    const int e = 4 * (u * kSpThreads + tid);
+                    if (e < nel) {
+                        const int rr = (int)__umulhi((unsigned)e, s.y_magic), y = e - rr * s.Y;
+                        const bool outside = (unsigned)(cur.e_lo + e) >= e_hi;   // (the quad's row)
+                        float* dst = dl + rr * s.P + (s.ky - 1 - s.py) + y;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float d = g[4 * u + k];
+                            if (out) d = (o[4 * u + k] > 0.f) ? d * (1.f - o[4 * u + k] * o[4 * u + k]) : 0.f;
+                            dst[k] = outside ? 0.f : d;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int e = u * kSpThreads + tid;
+                    if (e < nel) {
+                        const int rr = (int)__umulhi((unsigned)e, s.y_magic), y = e - rr * s.Y;
+                        float d = g[u];
+                        if (out) d = (o[u] > 0.f) ? d * (1.f - o[u] * o[u]) : 0.f;
+                        if ((unsigned)(cur.e_lo + e) >= e_hi) d = 0.f;   // a row outside the grid
+                        dl[rr * s.P + (s.ky - 1 - s.py) + y] = d;
+                    }
                 }
             }
             // ---- the lists: chunk tid came with the prefetch; a job with more than 512 chunks fetches the rest now
@@ -656,8 +693,8 @@ bool plan_sparse(int B, int Z, int X, int Y, int kz, int kx, int ky, int tile_by
     int txr = cap_bytes / Y;
     if (txr < 1) txr = 1;
     if (txr > X) txr = X;
-    while (txr > 1 && (txr + kx - 1) * Y > kSpStage * kSpThreads) --txr;
-    if ((txr + kx - 1) * Y > kSpStage * kSpThreads) return false;
+    while (txr > 1 && (txr + kx - 1) * Y > 6 * kSpThreads) --txr;
+    if ((txr + kx - 1) * Y > 6 * kSpThreads) return false;
     s->TXR = txr;
     s->nxt = (X + txr - 1) / txr;
     s->DR = txr + kx - 1;
@@ -723,6 +760,10 @@ int sn::corr_sparse_launch(const void* x, const void* gout, const void* out, int
         return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_corr_ws: shape outside the sparse correlation kernels");
     SparseShape& s = p.s;
     s.vec = (Y % 8 == 0) && ((uintptr_t)x % 8 == 0);
+    {   // quads of the delta tile: 2 x 4 x 512 elements at most, whole rows of a multiple of four, aligned pointers
+        const size_t ga = g_dtype == SN_BF16 ? 8 : 16;
+        s.vec4 = (Y % 4 == 0) && (s.DR * Y <= 8 * kSpThreads) && ((uintptr_t)gout % ga == 0) && (!out || (uintptr_t)out % ga == 0);
+    }
     s.dbg = sn::debug_env_int("SN_K4S_SKIP");
     float* partial = reinterpret_cast<float*>(ws);
     int* counts = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + p.off_counts);
