@@ -210,3 +210,43 @@ def test_one_sgd_step_moves_the_loss(hip_device):
     with torch.no_grad():
         model(x)  # like the reference, the frozen last coefficient is refreshed by the next forward
     assert abs(sum(float(p.detach()) for p in model.lambdas_dict.values()) - 1.0) < 1e-5  # convexity is maintained
+
+
+def test_round3_entry_points_refuse_bad_arguments(hip_device):
+    """sn_conv_corr_ws with a workspace too small for even the partial rows, sn_voxel_occupancy_fused_bank with a bank that
+    is not 9 x 9 x 9 or a misaligned blob, sn_conv_fused_v without a verdict word: an error code and a message, no launch."""
+    import ctypes
+    lib = _hip.load()
+    x = (torch.rand(1, 1, 8, 8, 16, device=hip_device) < 0.2)
+    g = torch.randn(1, 1, 8, 8, 16, device=hip_device)
+    C = torch.empty(27, device=hip_device)
+    need = int(lib.sn_conv_corr_ws_bytes(_hip.SN_OCC8, 1, 8, 8, 16, 3, 3, 3))
+    assert need >= int(lib.sn_conv_corr_blocks(1, 8, 8, 16)) * 27 * 4
+    small = torch.empty(64, dtype=torch.uint8, device=hip_device)
+    rc = lib.sn_conv_corr_ws(x.data_ptr(), _hip.SN_OCC8, g.data_ptr(), None, _hip.SN_F32, 1, 8, 8, 16, 3, 3, 3,
+                             small.data_ptr(), 64, C.data_ptr(), None)
+    assert rc != 0 and b"workspace" in lib.sn_last_error()
+    # a workspace with room for the partial rows only: served by the GEMM form, same numbers as the gather up to fp32 order
+    rows_only = int(lib.sn_conv_corr_blocks(1, 8, 8, 16)) * 27 * 4
+    ws = torch.empty(rows_only, dtype=torch.uint8, device=hip_device)
+    rc = lib.sn_conv_corr_ws(x.data_ptr(), _hip.SN_OCC8, g.data_ptr(), None, _hip.SN_F32, 1, 8, 8, 16, 3, 3, 3,
+                             ws.data_ptr(), rows_only, C.data_ptr(), None)
+    assert rc == 0
+    ref = _hip.conv_corr(x, g, None, (3, 3, 3)).reshape(-1)
+    assert (C - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    # the rider entry: a 9 x 5 x 5 bank is refused before anything is launched
+    model = sna.SceneNet({"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)).to(hip_device)
+    with pytest.raises(sna.HipLibraryError):
+        model.bank_rider(hip_device)
+    pts = torch.rand(100, 3, dtype=torch.float64, device=hip_device)
+    off = torch.tensor([0, 100], dtype=torch.int64, device=hip_device)
+    params, kinds = model.packed_params(hip_device)
+    bank = torch.empty((3, 9, 9, 9), device=hip_device)
+    prep = torch.empty(_hip.SN_CONV_PREP_BYTES + 16, dtype=torch.uint8, device=hip_device)
+    with pytest.raises(sna.HipLibraryError, match="16-byte"):
+        _hip.voxel_occupancy_fused(pts, None, off, (32, 32, 32), out_dtype=torch.bool,
+                                   bank_rider=(params, kinds, bank, prep[4:4 + _hip.SN_CONV_PREP_BYTES]))
+    out = torch.empty(x.shape, device=hip_device)
+    rc = lib.sn_conv_fused_v(x.data_ptr(), _hip.SN_OCC8, bank.data_ptr(), params.data_ptr(), 1, 8, 8, 16, 3, 9, 9, 9,
+                             out.data_ptr(), _hip.SN_F32, None, 0, None)
+    assert rc != 0 and b"null" in lib.sn_last_error()
