@@ -198,6 +198,19 @@ int sn_conv_fused(const void* x, int x_dtype, const float* bank, const float* la
 int sn_conv_fused_v(const void* x, int x_dtype, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
                     int kz, int kx, int ky, void* out, int out_dtype, int32_t* verdict, int assume_served,
                     sn_stream_t stream);
+/* The per-(bank, coefficients) work of sn_conv_fused -- K* = sum_g lambda_g K_g, its 24-bit fixed point, the worst-case
+ * error bound and the Toeplitz digit tables: ~8 us that every workgroup of the kernel otherwise spends for itself -- once,
+ * into a caller-owned blob of sn_conv_fused_prep_bytes(kz, kx, ky) bytes (16-byte aligned; 0: kernel extent not served),
+ * and the forward on that blob: same results bit for bit.  The blob carries the guard's verdict at the tolerance in force
+ * when it was written (sn_conv_fused_v's word: byte offset bytes - 12); assume_served as there.  The riders of
+ * sn_voxel_occupancy_fused_bank can write the blob too (lin_prep). */
+size_t sn_conv_fused_prep_bytes(int kz, int kx, int ky);
+int sn_conv_fused_prep(const float* bank, const float* lambdas, int G, int kz, int kx, int ky, void* blob,
+                       sn_stream_t stream);
+int sn_conv_fused_prepared(const void* x, int x_dtype, const float* bank, const float* lambdas, const void* blob, int B,
+                           int Z, int X, int Y, int G, int kz, int kx, int ky, void* out, int out_dtype, int assume_served,
+                           sn_stream_t stream);
+
 
 /* 1 when sn_conv_fused serves a [B,1,Z,X,Y] SN_OCC8 grid with a [kz,kx,ky] kernel (Y % 4, the ky window, the tables and
  * the halo within 160 KiB of LDS), else 0: the caller's dispatch predicate, from the same plan the launch uses. */

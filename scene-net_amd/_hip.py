@@ -76,6 +76,9 @@ SYMBOLS = {
                         + [_P, _P, _P, _P, _P]),
     "sn_param_penalty": (c_int, [_P, _P, _I, ctypes.c_float, _I, _P, _P, _P]),
     "sn_loss_backward": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _I, _P, _P, _P, _P]),
+    "sn_conv_fused_prep_bytes": (ctypes.c_size_t, [_I, _I, _I]),
+    "sn_conv_fused_prep": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "sn_conv_fused_prepared": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "sn_conv_fused_v": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P]),
     "sn_loss_forward_m": (c_int, [_P, _I, _P, _I, _I, ctypes.c_int64, _P, _P, _I, _I] + [ctypes.c_double] * 6
                           + [_P, _P, _P, _P, _P, _P]),
@@ -399,13 +402,20 @@ def conv_fused_supported(x: torch.Tensor, kernel_size: Sequence[int]) -> bool:
 @_on_tensor_device
 def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
                out_dtype: torch.dtype = torch.float32, verdict: Optional[torch.Tensor] = None,
-               assume_served: bool = False) -> torch.Tensor:
+               assume_served: bool = False, prep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu(tanh(conv3d(x, sum_g lambda_g K_g))) [B,1,Z,X,Y] (sn_conv_fused): the forward output through linearity.
     verdict: a caller-owned int32 [1] device tensor that receives the guard's verdict (sn_conv_fused_v); assume_served:
     the caller has read it as 0 for these weights / coefficients / tolerance -- the gated fp32 launches are left out."""
     B, _, Z, X, Y = x.shape
     G, kz, kx, ky = bank.shape
     out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device)
+    if prep is not None:   # the tables come from a blob (conv_fused_prep, or the riders of the voxelisation): same bits
+        rc = load().sn_conv_fused_prepared(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
+                                           _ptr(lambdas, torch.float32, "lambdas"), _ptr(prep, torch.uint8, "prep"), B, Z,
+                                           X, Y, G, kz, kx, ky, _ptr(out), _DT_OUT[out_dtype], int(bool(assume_served)),
+                                           _stream())
+        _check(rc, "sn_conv_fused_prepared")
+        return out
     if verdict is None:
         rc = load().sn_conv_fused(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
                                   _ptr(lambdas, torch.float32, "lambdas"), B, Z, X, Y, G, kz, kx, ky, _ptr(out),
@@ -417,6 +427,33 @@ def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
                                     _stream())
     _check(rc, "sn_conv_fused")
     return out
+
+
+def conv_fused_prep_bytes(kernel_size: Sequence[int]) -> int:
+    kz, kx, ky = (int(k) for k in kernel_size)
+    return int(load().sn_conv_fused_prep_bytes(kz, kx, ky))
+
+
+@_on_tensor_device
+def conv_fused_prep(bank: torch.Tensor, lambdas: torch.Tensor, blob: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sn_conv_fused_prep: the fused forward's per-(bank, coefficients) tables into a blob (uint8) conv_fused(prep=) uses."""
+    G, kz, kx, ky = bank.shape
+    nbytes = conv_fused_prep_bytes((kz, kx, ky))
+    if nbytes == 0:
+        raise HipLibraryError(f"sn_conv_fused_prep: kernel {kz}x{kx}x{ky} is outside the combined kernel")
+    if blob is None:
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=bank.device)
+    elif blob.dtype != torch.uint8 or blob.numel() < nbytes:
+        raise HipLibraryError(f"blob must be uint8 with at least {nbytes} bytes")
+    _check(load().sn_conv_fused_prep(_ptr(bank, torch.float32, "bank"), _ptr(lambdas, torch.float32, "lambdas"), G, kz, kx,
+                                     ky, _ptr(blob, torch.uint8, "blob"), _stream()), "sn_conv_fused_prep")
+    return blob
+
+
+def conv_fused_prep_verdict(blob: torch.Tensor, kernel_size: Sequence[int]) -> torch.Tensor:
+    """view of the guard's verdict word (int32 [1]) inside a fused-forward blob"""
+    n = conv_fused_prep_bytes(kernel_size)
+    return blob[n - 12:n - 8].view(torch.int32)
 
 
 @_on_tensor_device

@@ -24,7 +24,10 @@ int conv_bank_group(const void* x, int x_dtype, const float* bank, const float* 
                     int G, int Gtot, int g0, int head, int kz, int kx, int ky, void* act, void* out, int out_dtype,
                     sn_stream_t stream);   // conv.hip
 int conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G, int kz,
-                   int kx, int ky, void* out, int out_dtype, hipStream_t stream, int32_t* verdict = nullptr, bool assume_served = false);
+                   int kx, int ky, void* out, int out_dtype, hipStream_t stream, int32_t* verdict = nullptr, bool assume_served = false,
+                   const void* prep = nullptr);
+int conv_fused_prep_launch(const float* bank, const float* lambdas, int G, int kz, int kx, int ky, void* blob,
+                           hipStream_t stream);
 }
 
 namespace {
@@ -42,27 +45,11 @@ __device__ __forceinline__ float relu_tanh(float v) {
     return (v != v) ? v : r;
 }
 
-constexpr int kThreads = 512;
-constexpr int kWaves = kThreads / 64;
-constexpr int TZ = 8, TX = 16, TY = 64;  // workgroup tile: one z plane per wave, 16 rows (N), 4 strips of 16 y (M)
-constexpr int YB = 80;                   // halo bytes per row (64 + 16) = 5 chunks of 16 bytes
-// The halo is stored CHUNK-MAJOR, [chunk c][row r] x 16 bytes with the rows padded to a multiple of 16: the 16 lanes
-// one ds_read_b128 cycle serves (8 with a window's first chunk, 8 with its second) then fall on 16 distinct 16-byte
-// bank groups.
-constexpr int kMaxLds = 160 * 1024;
+#include "conv_lin_tables.inc"   // LinShape, lin_plan, lin_tables: the per-bank work, shared with voxel.hip's rider
 
-struct LinShape {
-    int B, Z, X, Y, G;
-    int kz, kx, ky, pz, px, py;
-    int nzt, nxt, nyt, ntiles;
-    int npairs, nsteps;   // kernel rows (dz,dx); MFMA steps = ceil(npairs / 2)
-    int XP, rows, NRP;    // halo rows per z plane, total halo rows, rows padded to a multiple of 16
-    int PYA;              // halo origin in y = y0 - PYA, PYA = roundup(py, 4) (aligned global dwords)
-    sn::Gate gate;       // run only if every condition holds (common.h: Gate)
-    int32_t* route;       // out: 1 = K*'s quantisation bound exceeded (the gated fp32 launches behind take over), else 0
-    float tol;            // bound on the worst-case pre-activation error allowed here (<= 0: no check)
-    int dbg;              // timing experiments (SN_CONV_LIN_DBG): 1 prologue only, 2 no MFMA loop, 4 no epilogue, 16 no deferral
-};
+constexpr int kThreads = kLinThreads;
+constexpr int TZ = kLinTZ, TX = kLinTX, TY = kLinTY, YB = kLinYB;
+constexpr int kMaxLds = kLinMaxLds;
 
 #ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/lin_timing.py
 __device__ unsigned long long g_lin_t[1024 * 16];   // per workgroup: 0 start, 1 tables done, 2 end, 3 tiles, 8.. per wave
@@ -89,8 +76,6 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
-    const int ntaps = s.kz * s.kx * s.ky;
-
     const size_t V = (size_t)s.Z * s.X * s.Y;
     // halo rows (z0 - pz .., x0 - px ..), columns y0 - PYA .. + YB, read as aligned global dwords into registers
     // (kHaloRegs per thread; larger halos take a synchronous remainder pass)
@@ -157,165 +142,23 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #define SN_LT(k) do {} while (0)
 #endif
     SN_LT(4);
-    // ---- prologue: K* = sum_g lambda_g K_g, its 24-bit fixed point, the Toeplitz digit table
-    float mx = 0.0f;
-    float w0[16], w1[16], l[16];
-    auto kload = [&](int t0, int g0) {   // two taps x 16 kernels: 32 bank loads (+ the lambdas) in flight, one latency
-        const int t1 = t0 + kThreads;
-        const int t0c = t0 < ntaps ? t0 : 0, t1c = t1 < ntaps ? t1 : t0c;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int g = g0 + u < s.G ? g0 + u : s.G - 1;
-            w0[u] = bank[(size_t)g * ntaps + t0c];
-            w1[u] = bank[(size_t)g * ntaps + t1c];
-            l[u] = g0 + u < s.G ? lambdas[g] : 0.0f;
-        }
-    };
-    // the first tile's halo is requested first and travels while the tables are built ([measured] the bank loads ahead
-    // of it instead: the prologue got 0.6 us longer -- the halo's 16 loads then queue behind 48 others)
+    // ---- prologue: the tables -- copied from a prepared blob (sn_conv_fused_prep / a rider of the voxelisation), or built here
+    // the first tile's halo is requested first and travels meanwhile ([measured] the bank loads ahead of it instead: the
+    // prologue got 0.6 us longer -- the halo's 16 loads then queue behind 48 others)
     if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);
-    for (int t0 = tid; t0 < ntaps; t0 += 2 * kThreads) {
-        const int t1 = t0 + kThreads;
-        float a0 = 0.0f, a1 = 0.0f;
-        for (int g0 = 0; g0 < s.G; g0 += 16) {   // the fp32 chain in kernel order
-            kload(t0, g0);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                a0 = fmaf(l[u], w0[u], a0);
-                a1 = fmaf(l[u], w1[u], a1);
-            }
-        }
-        kstar[t0] = a0;
-        if (t1 < ntaps) kstar[t1] = a1;
-        const float aa0 = fabsf(a0), aa1 = (t1 < ntaps) ? fabsf(a1) : 0.0f;
-        mx = (aa0 <= 3.0e38f) ? fmaxf(mx, aa0) : __int_as_float(0x7fc00000);  // NaN / inf poisons the kernel
-        mx = (aa1 <= 3.0e38f) ? fmaxf(mx, aa1) : __int_as_float(0x7fc00000);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float u = __shfl_xor(mx, o, 64);
-        mx = (mx != mx || u != u) ? __int_as_float(0x7fc00000) : fmaxf(mx, u);
-    }
-    float* wmax = misc + 4;  // no static __shared__: the kernel asks for the whole 160 KiB dynamically
-    if (lane == 0) wmax[wave] = mx;
-    __syncthreads();
-    SN_LT(5);
-    // 24-bit fixed point over the whole range of three balanced digits: Q = rint(K* . S) in fp64, S = 8355711 / max|K*|
-    double S = 0.0, invS = 0.0;
-    {
-        float m = 0.0f;
-        for (int w = 0; w < kWaves; ++w) m = (m != m || wmax[w] != wmax[w]) ? __int_as_float(0x7fc00000) : fmaxf(m, wmax[w]);
-        if (m > 0.0f) { S = 8355711.0 / (double)m; invS = (double)m / 8355711.0; }   // NaN: comparison false, S = 0 and the scale below is NaN
-        if (tid == 0) misc[0] = (m != m) ? m : (float)((double)m / 8355711.0);
-    }
-    double ep = 0.0, en = 0.0;   // this thread's share of the positive / negative quantisation errors
-    // Each (kernel row p, digit d) as a zero-padded byte row R[64] with tap dy at byte 32 + dy; a table entry is the
-    // 16-byte window of that row starting at byte 32 + 16 h - m - delta: five aligned dwords and four v_alignbyte
-    // instead of quantising sixteen taps per entry (the table build was ~4 us of the prologue).
-    constexpr int RW = 17;   // dwords per padded row (64 bytes + 1 zero dword for the look-ahead of the funnel shift)
-    uint32_t* rpad = reinterpret_cast<uint32_t*>(kstar + ((ntaps + 3) & ~3));   // [npairs][3][RW]
-    for (int i = tid; i < s.npairs * 3 * RW; i += kThreads) rpad[i] = 0u;
-    __syncthreads();
-    const int ngrp = (s.ky + 3) >> 2;   // dwords that hold taps: bytes 32 .. 32 + ky
-    for (int i = tid; i < s.npairs * ngrp; i += kThreads) {
-        const int p = i / ngrp, gq = i - p * ngrp;
-        uint32_t w0 = 0u, w1 = 0u, w2 = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int dy = 4 * gq + j;
-            if (dy < s.ky) {
-                const double wv = (double)kstar[p * s.ky + dy];
-                int Q = __double2int_rn(wv * S);
-                if (S > 0.0) {
-                    const double e = (double)Q * invS - wv;
-                    ep += e > 0.0 ? e : 0.0;
-                    en += e < 0.0 ? -e : 0.0;
-                }
-                const int d0 = ((Q + 128) & 255) - 128;
-                Q = (Q - d0) >> 8;
-                const int d1 = ((Q + 128) & 255) - 128;
-                const int d2 = (Q - d1) >> 8;
-                w0 |= (uint32_t)(d0 & 255) << (8 * j);
-                w1 |= (uint32_t)(d1 & 255) << (8 * j);
-                w2 |= (uint32_t)(d2 & 255) << (8 * j);
-            }
-        }
-        rpad[(p * 3 + 0) * RW + 8 + gq] = w0;
-        rpad[(p * 3 + 1) * RW + 8 + gq] = w1;
-        rpad[(p * 3 + 2) * RW + 8 + gq] = w2;
-    }
-    // the exact worst case of the quantisation error over all binary inputs: max(sum of the positive errors, sum of the
-    // negative ones).  Above the tolerance the launch is not run here: *route = 1 hands it to the fp32 contraction.
-    double* esum = reinterpret_cast<double*>(misc + 16);   // [kWaves][2]
-    if (s.tol > 0.0f) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            ep += __shfl_xor(ep, o, 64);
-            en += __shfl_xor(en, o, 64);
-        }
-        if (lane == 0) { esum[2 * wave] = ep; esum[2 * wave + 1] = en; }
-    }
-    __syncthreads();
-    if (s.tol > 0.0f) {
-        double tp = 0.0, tn = 0.0;
-        for (int w = 0; w < kWaves; ++w) { tp += esum[2 * w]; tn += esum[2 * w + 1]; }
-        const bool exceeded = (tp > tn ? tp : tn) > (double)s.tol;
-        if (blockIdx.x == 0 && tid == 0 && s.route) *s.route = exceeded ? 1 : 0;
-        if (exceeded) return;   // the halo loads requested above have register destinations: nothing is left in flight
-    } else if (blockIdx.x == 0 && tid == 0 && s.route) {
-        *s.route = 0;
-    }
-    SN_LT(6);
-    for (int i = tid; i < (s.nsteps + 1) * 64; i += kThreads) {
-        const int st = i >> 6, l = i & 63;
-        const int m = l & 15, qq = l >> 4;
+    if (s.prep) {
+        const LinBlob lb = lin_blob_layout(s.nsteps, kW24);
+        const int32_t verdict = *reinterpret_cast<const int32_t*>(s.prep + lb.tail_off + 4);
+        if (verdict != 0 && s.tol > 0.0f) return;   // the bound was over the tolerance: the gated fp32 launches behind take over
+        const uint4* src = reinterpret_cast<const uint4*>(s.prep);
+        for (int i = tid; i < (s.nsteps + 1) * 3 * 64; i += kThreads) At[i] = src[i];
         if constexpr (kW24) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                uint32_t o[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {   // piece pi: window bytes 8 t .. 8 t + 7 of kernel row p
-                    const int pi = 8 * st + 2 * qq + e;
-                    const int p = pi / 3, t = pi - 3 * p;
-                    if (p < s.npairs) {
-                        const int s0 = 32 + 8 * t - m - (s.PYA - s.py);   // 14 .. 48
-                        const uint32_t* r = rpad + (p * 3 + d) * RW + (s0 >> 2);
-                        const uint32_t v0 = r[0], v1 = r[1], v2 = r[2];
-                        o[2 * e] = __builtin_amdgcn_alignbyte(v1, v0, s0 & 3);
-                        o[2 * e + 1] = __builtin_amdgcn_alignbyte(v2, v1, s0 & 3);
-                    }
-                }
-                At[(st * 3 + d) * 64 + l] = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        } else {
-            const int p = 2 * st + (qq >> 1);
-            const int s0 = 32 + 16 * (qq & 1) - m - (s.PYA - s.py);   // first byte of this lane's window (14 .. 48)
-            const int wq = s0 >> 2, sh = s0 & 3;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                uint32_t o[4] = {0u, 0u, 0u, 0u};
-                if (p < s.npairs) {
-                    const uint32_t* r = rpad + (p * 3 + d) * RW + wq;
-                    uint32_t v[5];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) v[j] = r[j];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_alignbyte(v[j + 1], v[j], sh);
-                }
-                At[(st * 3 + d) * 64 + l] = make_uint4(o[0], o[1], o[2], o[3]);
-            }
+            const int* ts = reinterpret_cast<const int*>(s.prep + lb.tab_off);
+            for (int i = tid; i < (s.nsteps + 3) * 8; i += kThreads) offtab[i] = ts[i];
         }
-    }
-    if constexpr (kW24) {   // piece -> halo byte offset (row (dz, dx), chunk t >> 1, half t & 1); past the end: 0
-        for (int pi = tid; pi < (s.nsteps + 3) * 8; pi += kThreads) {
-            const int p = pi / 3, t = pi - 3 * p;
-            int off = 0;
-            if (p < s.npairs) {
-                const int dz = p / s.kx, dx = p - dz * s.kx;
-                off = ((t >> 1) * s.NRP + dz * s.XP + dx) * 16 + 8 * (t & 1);
-            }
-            offtab[pi] = off;
-        }
+        if (tid == 0) misc[0] = *reinterpret_cast<const float*>(s.prep + lb.tail_off);
+    } else {
+        if (lin_tables<kW24>(bank, lambdas, s, At, offtab, misc, misc, kstar, s.route, blockIdx.x == 0)) return;
     }
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
     const float scale = misc[0];
@@ -516,6 +359,21 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #endif
 }
 
+// The tables into a blob, by one workgroup: what every workgroup of conv_lin_i8_kernel otherwise builds for itself
+// ([measured] C2: 8.5 of the kernel's ~50 us; tools/debug/lin_floor.py).
+template <bool kW24>
+__global__ __launch_bounds__(kThreads) void conv_lin_prep_kernel(const float* __restrict__ bank,
+                                                                 const float* __restrict__ lambdas, LinShape s,
+                                                                 uint8_t* __restrict__ blob) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float* misc = reinterpret_cast<float*>(lds);          // [64]
+    float* kstar = misc + 64;
+    const LinBlob lb = lin_blob_layout(s.nsteps, kW24);
+    lin_tables<kW24>(bank, lambdas, s, reinterpret_cast<uint4*>(blob), reinterpret_cast<int*>(blob + lb.tab_off),
+                     reinterpret_cast<float*>(blob + lb.tail_off), misc, kstar,
+                     reinterpret_cast<int32_t*>(blob + lb.tail_off + 4), true);
+}
+
 int num_cus() {
     static thread_local int cached = 0;
     if (!cached) {
@@ -531,32 +389,6 @@ int num_cus() {
 
 namespace {
 // The shape plan, shared by the launch and by sn_conv_fused_supported: false when the shape is outside this kernel.
-bool lin_plan(int B, int Z, int X, int Y, int G, int kz, int kx, int ky, LinShape& s, size_t& lds, bool& w24) {
-    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || kz <= 0 || kx <= 0 || ky <= 0 || Y % 4 != 0) return false;
-    s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G;
-    s.kz = kz; s.kx = kx; s.ky = ky;
-    s.pz = (kz - 1) / 2; s.px = (kx - 1) / 2; s.py = (ky - 1) / 2;
-    s.PYA = (s.py + 3) & ~3;
-    if (s.PYA - s.py + 15 + ky - 1 >= 32) return false;  // a 16-y strip's window must fit 32 halo bytes
-    if (TY - 16 + 32 > YB) return false;
-    s.nzt = (Z + TZ - 1) / TZ; s.nxt = (X + TX - 1) / TX; s.nyt = (Y + TY - 1) / TY;
-    const long long nt = (long long)B * s.nzt * s.nxt * s.nyt;
-    if (nt > 0x7fffffff) return false;
-    s.ntiles = (int)nt;
-    s.npairs = kz * kx;
-    // 24-byte packing of the kernel rows when a strip's window fits 24 halo bytes (ky <= 9 with PYA == py)
-    w24 = (s.PYA - s.py + 15 + ky - 1 < 24) && !sn::option_extra(sn::kOptConvLinNo24);
-    s.nsteps = w24 ? (3 * s.npairs + 7) / 8 : (s.npairs + 1) / 2;   // odd counts end with a lone step after the pairs
-    s.XP = TX + kx - 1;
-    s.rows = (TZ + kz - 1) * s.XP;
-    s.NRP = (s.rows + 15) & ~15;
-    const size_t halo = (size_t)s.NRP * YB;
-    // prologue scratch aliasing the halo: K* and the padded digit rows
-    const size_t kst = (((size_t)kz * kx * ky + 3) & ~(size_t)3) * sizeof(float) + (size_t)kz * kx * 3 * 17 * 4;
-    lds = (size_t)(s.nsteps + 1) * 3 * 64 * 16 + 256 + (w24 ? (size_t)(s.nsteps + 3) * 8 * 4 : 0) +
-          (halo > kst ? halo : kst) + 16;
-    return lds <= (size_t)kMaxLds;
-}
 }  // namespace
 
 extern "C" int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int kx, int ky) {
@@ -569,7 +401,7 @@ extern "C" int sn_conv_fused_supported(int B, int Z, int X, int Y, int kz, int k
 // returns SN_ERR_UNSUPPORTED (without touching the error text) when the shape is outside this kernel
 int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas, int B, int Z, int X, int Y, int G,
                        int kz, int kx, int ky, void* out, int out_dtype, hipStream_t stream, int32_t* verdict,
-                       bool assume_served) {
+                       bool assume_served, const void* prep) {
     if (((uintptr_t)x % 4) || ((uintptr_t)out % (out_dtype == SN_BF16 ? 8 : 16))) return SN_ERR_UNSUPPORTED;
     LinShape s;
     size_t lds = 0;
@@ -582,7 +414,12 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     s.tol = sn::option_conv_i8_tolerance();
     if (out_dtype == SN_BF16) s.tol = 0.0f;   // bf16 storage rounds at 2^-9: the 24-bit fixed point is not what limits it
     s.route = nullptr;
-    if (s.tol > 0.0f) {
+    s.prep = static_cast<const uint8_t*>(prep);
+    if (prep) {
+        // the verdict was written with the tables (at the tolerance in force then): the gated launches read it there
+        s.route = s.tol > 0.0f ? reinterpret_cast<int32_t*>(const_cast<uint8_t*>(s.prep) + lin_blob_layout(s.nsteps, w24).tail_off + 4)
+                               : nullptr;
+    } else if (s.tol > 0.0f) {
         s.route = verdict ? verdict : sn::device_flag_slot(stream);   // (a caller-owned word can be read back: sn_conv_fused_v)
         if (!s.route) s.tol = 0.0f;   // no flag memory: run unguarded rather than fail
     }
@@ -706,6 +543,61 @@ extern "C" int sn_conv_fused(const void* x, int x_dtype, const float* bank, cons
                                       sn::as_stream(stream));
     if (rc == SN_ERR_UNSUPPORTED)
         return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused: shape outside the kernel (Y %% 4, ky window, LDS); use "
+                                            "sn_conv_bank");
+    return rc;
+}
+
+extern "C" size_t sn_conv_fused_prep_bytes(int kz, int kx, int ky) {
+    LinShape s;
+    size_t lds = 0;
+    bool w24 = false;
+    if (!lin_plan(1, TZ, TX, TY, 1, kz, kx, ky, s, lds, w24)) return 0;
+    return lin_blob_layout(s.nsteps, w24).bytes;
+}
+
+// the tables of (bank, lambdas) into `blob` (sn_conv_fused_prep_bytes, 16-byte aligned), with the guard's verdict at the
+// tolerance in force now: one workgroup
+int sn::conv_fused_prep_launch(const float* bank, const float* lambdas, int G, int kz, int kx, int ky, void* blob,
+                               hipStream_t stream) {
+    LinShape s;
+    size_t lds = 0;
+    bool w24 = false;
+    if (!lin_plan(1, TZ, TX, TY, G, kz, kx, ky, s, lds, w24)) return SN_ERR_UNSUPPORTED;
+    s.gate = sn::current_gate();
+    s.tol = sn::option_conv_i8_tolerance();
+    s.route = nullptr;
+    s.prep = nullptr;
+    s.dbg = 0;
+    const size_t scratch = 256 + (((size_t)kz * kx * ky + 3) & ~(size_t)3) * sizeof(float) + (size_t)kz * kx * 3 * 17 * 4 + 16;
+    if (w24) hipLaunchKernelGGL(conv_lin_prep_kernel<true>, dim3(1), dim3(kThreads), scratch, stream, bank, lambdas, s, (uint8_t*)blob);
+    else hipLaunchKernelGGL(conv_lin_prep_kernel<false>, dim3(1), dim3(kThreads), scratch, stream, bank, lambdas, s, (uint8_t*)blob);
+    return sn::check_launch("sn_conv_fused_prep");
+}
+
+extern "C" int sn_conv_fused_prep(const float* bank, const float* lambdas, int G, int kz, int kx, int ky, void* blob,
+                                  sn_stream_t stream) {
+    if (!bank || !lambdas || !blob) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_prep: null pointer");
+    if (G <= 0 || kz <= 0 || kx <= 0 || ky <= 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_prep: non-positive extent");
+    if ((uintptr_t)blob % 16) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_prep: blob must be 16-byte aligned");
+    const int rc = sn::conv_fused_prep_launch(bank, lambdas, G, kz, kx, ky, blob, sn::as_stream(stream));
+    if (rc == SN_ERR_UNSUPPORTED)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused_prep: kernel %d x %d x %d outside the combined kernel", kz, kx, ky);
+    return rc;
+}
+
+extern "C" int sn_conv_fused_prepared(const void* x, int x_dtype, const float* bank, const float* lambdas, const void* blob,
+                                      int B, int Z, int X, int Y, int G, int kz, int kx, int ky, void* out, int out_dtype,
+                                      int assume_served, sn_stream_t stream) {
+    if (!x || !bank || !lambdas || !out || !blob) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_prepared: null pointer");
+    if (B <= 0 || Z <= 0 || X <= 0 || Y <= 0 || G <= 0 || kz <= 0 || kx <= 0 || ky <= 0)
+        return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_prepared: non-positive extent");
+    if (x_dtype != SN_OCC8)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused_prepared: binary occupancy (SN_OCC8) input only; use sn_conv_bank");
+    if ((uintptr_t)blob % 16) return sn::fail(SN_ERR_INVALID_ARG, "sn_conv_fused_prepared: blob must be 16-byte aligned");
+    const int rc = sn::conv_fused_lin((const uint8_t*)x, bank, lambdas, B, Z, X, Y, G, kz, kx, ky, out, out_dtype,
+                                      sn::as_stream(stream), nullptr, assume_served != 0, blob);
+    if (rc == SN_ERR_UNSUPPORTED)
+        return sn::fail(SN_ERR_UNSUPPORTED, "sn_conv_fused_prepared: shape outside the kernel (Y %% 4, ky window, LDS); use "
                                             "sn_conv_bank");
     return rc;
 }

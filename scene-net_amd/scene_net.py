@@ -327,23 +327,31 @@ class SceneNet(nn.Module):
         return res
 
     def fused_served(self, x: torch.Tensor, bank: torch.Tensor, lam: torch.Tensor, out_dtype: torch.dtype):
-        """sn_conv_fused on (bank, lam) of THIS model's current parameters: the guard's verdict is learnt as in
-        contract_prepared (asynchronously, keyed on the parameter versions and the tolerance), and once it has read
+        """sn_conv_fused on (bank, lam) of THIS model's current parameters, with what depends on them alone taken out of
+        the call: the kernel's tables (K*, its fixed point, the digit tables: ~8 us that every workgroup otherwise builds
+        for itself) are prepared into a blob once per parameter version (sn_conv_fused_prep -- like effective_lambdas'
+        cache; not inside a graph capture, which outlives the versions), and the guard's verdict is learnt as
+        in contract_prepared (asynchronously, keyed on the parameter versions and the tolerance): once it has read
         "served" the gated fp32 launches behind the combined kernel are left out."""
-        if out_dtype == torch.bfloat16:   # (runs unguarded: nothing to learn)
-            return _hip.conv_fused(x, bank, lam, out_dtype=out_dtype)
+        ks = tuple(int(k) for k in bank.shape[1:])
         key = (x.device, _hip.get_option("conv_i8_tolerance_ppb"),
                self._pack_cache[0] if self._pack_cache is not None else None,
                self._lambda_cache[0] if self._lambda_cache is not None else None)
-        state = self.__dict__.get("_fused_verdict")
-        if state is None or state[1].device != x.device:
-            state = (_hip.PreparedVerdict(), torch.zeros(1, dtype=torch.int32, device=x.device))
-            self.__dict__["_fused_verdict"] = state
-        verdict, word = state
-        served = verdict.served(key)
-        out = _hip.conv_fused(x, bank, lam, out_dtype=out_dtype, verdict=word, assume_served=served)
-        if not served:
-            verdict.note_words(word, key)
+        state = self.__dict__.get("_fused_state")
+        if state is None or state["blob"].device != x.device or state["ks"] != ks:
+            state = {"verdict": _hip.PreparedVerdict(), "ks": ks, "key": None,
+                     "blob": torch.empty(_hip.conv_fused_prep_bytes(ks), dtype=torch.uint8, device=x.device)}
+            self.__dict__["_fused_state"] = state
+        if torch.cuda.is_current_stream_capturing():
+            # a captured graph outlives these parameter versions: the kernel builds its tables itself, the fallback stays
+            return _hip.conv_fused(x, bank, lam, out_dtype=out_dtype)
+        if state["key"] != key:
+            _hip.conv_fused_prep(bank, lam, state["blob"])
+            state["key"] = key
+        served = state["verdict"].served(key)
+        out = _hip.conv_fused(x, bank, lam, out_dtype=out_dtype, prep=state["blob"], assume_served=served)
+        if not served and out_dtype != torch.bfloat16:   # (bf16 output runs unguarded: nothing to learn)
+            state["verdict"].note_words(_hip.conv_fused_prep_verdict(state["blob"], ks), key)
         return out
 
     def serves_prepared(self, x: torch.Tensor) -> bool:

@@ -356,7 +356,8 @@ def test_fused_forward_learns_its_verdict_and_drops_the_gated_launches(hip_devic
     with torch.no_grad():
         first = model(x)
         torch.cuda.synchronize()
-        verdict, word = model._fused_verdict
+        verdict = model._fused_state["verdict"]
+        word = _hip.conv_fused_prep_verdict(model._fused_state["blob"], (9, 9, 9))
         assert int(word.item()) == 0
         again = model(x)            # picks the read-back up: served
         assert verdict._state == 2
@@ -380,3 +381,33 @@ def test_fused_forward_learns_its_verdict_and_drops_the_gated_launches(hip_devic
             assert torch.equal(strict, _hip.conv_bank(x.view(torch.uint8), bank, lam, want_act=False, want_out=True)[1])
         finally:
             _hip.set_option("conv_i8_tolerance_ppb", 90000)
+
+
+@pytest.mark.parametrize("ks", [(9, 9, 9), (9, 5, 5), (6, 5, 6), (9, 7, 7)])
+def test_fused_forward_on_prepared_tables(hip_device, ks):
+    """sn_conv_fused_prep + sn_conv_fused_prepared == sn_conv_fused bit for bit (f32, f64, bf16 outputs; ragged grids); the
+    blob's verdict word is 0 for a bank within the tolerance and 1 -- with the fp32 contraction's result -- for a
+    tolerance nothing meets."""
+    torch.manual_seed(4)
+    model = sna.SceneNet({"cy": 2, "cone": 2, "neg": 1}, ks).to(hip_device)
+    bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+    blob = _hip.conv_fused_prep(bank, lam)
+    assert blob.numel() == _hip.conv_fused_prep_bytes(ks) > 0
+    for shape in [(2, 1, 64, 64, 64), (1, 1, 20, 33, 64), (3, 1, 9, 17, 128)]:
+        x = torch.rand(shape, device=hip_device) < 0.06
+        for dt in (torch.float32, torch.float64, torch.bfloat16):
+            want = _hip.conv_fused(x, bank, lam, out_dtype=dt)
+            got = _hip.conv_fused(x, bank, lam, out_dtype=dt, prep=blob)
+            assert torch.equal(want, got), (ks, shape, dt)
+    torch.cuda.synchronize()
+    assert int(_hip.conv_fused_prep_verdict(blob, ks).item()) == 0
+    _hip.set_option("conv_i8_tolerance_ppb", 1)
+    try:
+        strict = _hip.conv_fused_prep(bank, lam)
+        x = torch.rand(2, 1, 16, 16, 64, device=hip_device) < 0.06
+        got = _hip.conv_fused(x, bank, lam, prep=strict)
+        torch.cuda.synchronize()
+        assert int(_hip.conv_fused_prep_verdict(strict, ks).item()) == 1
+        assert torch.equal(got, _hip.conv_bank(x.view(torch.uint8), bank, lam, want_act=False, want_out=True)[1])
+    finally:
+        _hip.set_option("conv_i8_tolerance_ppb", 90000)
