@@ -237,7 +237,7 @@ def test_scene_net_picks_the_linear_forward_only_for_what_it_serves():
     assert sna.SceneNet.fused_forward is True
 
 
-@pytest.mark.parametrize("name", ["r01_final_bench.json", "r02_bench.json"])
+@pytest.mark.parametrize("name", ["r01_final_bench.json", "r02_bench.json", "r03_bench.json"])
 def test_committed_bench_line_keeps_the_contract(name):
     """profiles/<name> (stdout of bench.py on the MI355X box) carries every key the driver's contract names, the roofline
     and CPU-baseline objects, and internally consistent figures (round 2 adds the fp32 and cold figures and the ranks)."""
@@ -245,7 +245,7 @@ def test_committed_bench_line_keeps_the_contract(name):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = json.load(open(os.path.join(root, "profiles", name)))
-    if name.startswith("r02"):
+    if not name.startswith("r01"):
         for k in ("value_fp32", "ms_per_step_fp32", "value_cold", "ms_per_step_cold", "rccl_ranks", "per_rank_tiles_per_s"):
             assert k in d, k
         assert d["rccl_ranks"] == d["n_gpus"] == len(d["per_rank_tiles_per_s"])
@@ -263,6 +263,9 @@ def test_committed_bench_line_keeps_the_contract(name):
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    if name.startswith("r03"):   # round 3: the sustained figure, and the dominant kernel is the z-walk
+        assert d["value_sustained"] >= d["value"] and "conv_occ_i8z_kernel" in r["kernel"] and r["launches_timed"] >= 3
+        assert abs(d["sustained"]["value"] - tiles / (d["sustained"]["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
 def test_device_mismatch_is_refused_before_any_launch():
@@ -286,3 +289,30 @@ def test_voxelization_in_a_badly_forked_worker_says_what_to_do(monkeypatch):
     monkeypatch.setattr(torch.cuda, "_is_in_bad_fork", lambda: True)
     with pytest.raises(sna.HipLibraryError, match="spawn"):
         sna.Voxelization([15], vxg_size=(8, 8, 8))((np.zeros((4, 3)), np.zeros(4)))
+
+
+def test_prepared_verdict_is_copy_and_pickle_safe():
+    """_hip.PreparedVerdict lives in a module's __dict__ (contract_prepared / fused_served): copying or pickling the module
+    must neither fail on its event / pinned buffer nor carry a learnt verdict over to the copy."""
+    import copy
+    import pickle
+    from scene_net_amd import _hip
+    v = _hip.PreparedVerdict()
+    v._key, v._state = ("k",), 2
+    for w in (copy.deepcopy(v), pickle.loads(pickle.dumps(v))):
+        assert isinstance(w, _hip.PreparedVerdict) and w._key is None and w._state == 0
+
+
+def test_round3_entry_points_are_bound():
+    """every entry point added in round 3 is declared in the header, exported by the library and bound in _hip.SYMBOLS"""
+    from scene_net_amd import _hip
+    lib = _hip.load()
+    for name in ("sn_voxel_occupancy_fused_bank", "sn_voxel_occupancy_sized_bank", "sn_conv_corr_ws", "sn_conv_corr_ws_bytes",
+                 "sn_conv_fused_v", "sn_conv_fused_prep", "sn_conv_fused_prep_bytes", "sn_conv_fused_prepared",
+                 "sn_loss_forward_m", "sn_loss_backward_u", "sn_criterion_forward", "sn_criterion_backward",
+                 "sn_geneo_bank_prep", "sn_conv_bank_prep", "sn_conv_bank_prepared", "sn_conv_bank_prepared_served"):
+        assert name in _hip.SYMBOLS and hasattr(lib, name), name
+    assert lib.sn_version() >= 102
+    assert int(lib.sn_conv_fused_prep_bytes(9, 9, 9)) > 0 and int(lib.sn_conv_fused_prep_bytes(9, 9, 40)) == 0
+    assert int(lib.sn_conv_corr_ws_bytes(_hip.SN_OCC8, 32, 64, 64, 64, 9, 9, 9)) > \
+        int(lib.sn_conv_corr_ws_bytes(_hip.SN_F32, 32, 64, 64, 64, 9, 9, 9)) > 0
