@@ -15,6 +15,7 @@ cp $S/c4.txt $P/${TAG}_c4_bench.txt
 cp $S/conv_ab.txt $P/${TAG}_conv_ab.txt
 cp $S/train_bench.txt $P/${TAG}_train_bench.txt
 cp $S/train_bench_bf16.txt $P/${TAG}_train_bench_bf16.txt
+cp $S/train_kernel_stats.csv $P/${TAG}_train_kernel_stats.csv
 cp $S/step_host.txt $P/${TAG}_step_host.txt
 cp $S/k1_time.txt $P/${TAG}_k1_time.txt
 cp $S/corr_time.txt $P/${TAG}_corr_time.txt

@@ -17,6 +17,9 @@ echo kernel stats done
 python bench.py --gpus 2 --rehearse-on-one-gpu --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_rehearse2.json 2> $O/bench_rehearse2.err || echo "rehearsal failed"
 python bench.py --grid 128 --batch 32 --points 120000 --steps 10 --warmup 2 --no-cpu-baseline > $O/c3_bench.json 2> $O/c3.err
 python3 tools/train_step_bench.py --graph --iters 20 > $O/train_bench.txt 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 tools/train_step_bench.py --graph --iters 20 > $O/train_profiled.txt 2>&1 || true
+cp $(find $O/prof_train -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv || true
+rm -rf $O/prof_train
 python3 tools/train_step_bench.py --graph --iters 20 --bf16 > $O/train_bench_bf16.txt 2>&1 || true
 python tools/c4_bench.py --batch 32 > $O/c4.txt 2>&1 || true
 python tools/c4_bench.py --batch 32 --voxel-size 0.9 0.9 0.9 >> $O/c4.txt 2>&1 || true   # (0.9 m: the ~100 m scans fit 128^3)
