@@ -159,6 +159,16 @@ class SceneNet(nn.Module):
         object.__setattr__(self.lambdas_dict, "_sn_live", self._live)
         return self.lambdas_dict
 
+    def invalidate_caches(self) -> None:
+        """Drops everything derived from the parameters that is kept between calls (packed parameters, effective
+        coefficients, the fused forward's tables, the learnt guard verdicts).  The caches key on each parameter's identity
+        and `_version`, which every in-place op and every re-assignment changes -- but a write through `.data` (or through
+        a raw pointer) does not: call this after such a write."""
+        self._pack_cache = None
+        self._lambda_cache = None
+        for k in ("_fused_state", "_prepared_verdict", "_geneo_params_cache"):
+            self.__dict__.pop(k, None)
+
     def get_num_total_params(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 

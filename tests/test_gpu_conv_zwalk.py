@@ -370,6 +370,14 @@ def test_fused_forward_learns_its_verdict_and_drops_the_gated_launches(hip_devic
         assert verdict._state in (0, 1)
         torch.cuda.synchronize()
         assert torch.equal(model(x), changed)
+        # a write through .data is invisible to the version keys: invalidate_caches() is the documented way
+        model.lambdas_dict[name].data.mul_(0.5)
+        model.invalidate_caches()
+        halved = model(x)
+        assert not torch.equal(halved, changed) and model._fused_state["verdict"]._state in (0, 1)
+        torch.cuda.synchronize()
+        verdict = model._fused_state["verdict"]   # (a fresh state: new blob, new verdict)
+        word = _hip.conv_fused_prep_verdict(model._fused_state["blob"], (9, 9, 9))
         # an impossible tolerance: verdict 1, never "served", the fp32 contraction's result
         _hip.set_option("conv_i8_tolerance_ppb", 1)
         try:
