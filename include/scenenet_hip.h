@@ -36,7 +36,8 @@ typedef enum {
     SN_ERR_INVALID_ARG = -1,   /* null pointer, non-positive extent, bad enum        */
     SN_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for       */
     SN_ERR_LAUNCH = -3,        /* hipGetLastError() after a launch                   */
-    SN_ERR_NO_DEVICE = -4      /* no gfx950 device / HIP runtime unusable            */
+    SN_ERR_NO_DEVICE = -4,     /* no gfx950 device / HIP runtime unusable            */
+    SN_ERR_DEVICE_STATUS = -5  /* a kernel latched the sticky status: sn_device_status */
 } sn_status;
 
 /* SN_BF16: bfloat16 STORAGE of activations / their gradients in the training path (reference: `precision: 16`,
@@ -70,6 +71,18 @@ int sn_version(void);
  * (hipMalloc / hipMemset are illegal there).  Launches made while their stream is capturing draw words that are never
  * handed out again, so a captured graph owns its flags (see csrc/cabi.hip). */
 int sn_prepare_device(void);
+/* The sticky device status (round 4).  A kernel that cannot keep its contract does not return plausible numbers: it
+ * overwrites what it owns with NaN and latches a status in host-pinned words of its device --
+ *   1  a dependency spin of the z-walk contraction gave up (sn_conv_bank_prepared[_served]);
+ *   2  sn_conv_bank_prepared_served was called for a bank whose verdict is NOT "served" (a stale cached verdict);
+ *   3  a hand-over spin of an int8 tile kernel gave up (sn_conv_bank, x_dtype SN_OCC8 / SN_U8)
+ * -- and from then on EVERY sn_* entry that launches work fails with SN_ERR_DEVICE_STATUS (sn_last_error() says which code,
+ * which workgroup) until sn_device_status_clear().  Looking at the words is a host memory read: no synchronisation, nothing
+ * on the launch path.  sn_device_status: *code = 0 when healthy; detail2 (nullable) = {workgroup, ticket | verdict}.
+ * sn_device_status_clear synchronises the device first.  The reference has no counterpart (its conv3d cannot fail this
+ * way); this is the error behaviour of the hand-written path. */
+int sn_device_status(int* code, int* detail2);
+int sn_device_status_clear(void);
 /* Diagnostics: how many sn_conv_bank launches (this device, this process) the folded int8 kernel served [0], declined
  * because the bank was not symmetric in x and y [1], and handed to the fp32 kernel because the quantisation bound
  * exceeded the tolerance [2].  Synchronises the device.  (No reference counterpart.) */
@@ -91,7 +104,12 @@ int sn_device_count(void);
  *       contracted over 9 x 5 x 5 folded taps (exactly the same integer sums, a third of the MFMAs); the symmetry is
  *       checked on the device at every call, other banks take the unfolded kernel; 0 = never try
  *   "conv_i8_legacy" (default 0): 1 = sn_conv_bank uses the four-copy int8 kernel (conv_i8.hip) for every shape
- *       instead of the stride-4 kernel (conv_i8s.hip) it prefers for ky = 9 (A/B timing, parity tests of both). */
+ *       instead of the stride-4 kernel (conv_i8s.hip) it prefers for ky = 9 (A/B timing, parity tests of both).
+ *   "conv_i8z_variant" (default 2): the shape of the z-walk's tickets -- 0: rounds of two x-rows on 8 waves, 1: one round of
+ *       one x-row per ticket on 12 waves, 2: two such rounds per ticket.  Same results bit for bit (tested on all three).
+ *   "conv_i8z_inject_fault" (default 0): TEST HOOK.  1 = the next z-walk launches never report plane 0's first raw rows
+ *       as landed, so a dependency spin gives up (~0.5 s per launch): the way to see the loud failure path -- NaN outputs
+ *       and the sticky device status -- on the product build (tests/test_gpu_conv_zwalk.py). */
 int sn_set_option(const char* name, int value);
 int sn_get_option(const char* name);
 
@@ -170,14 +188,17 @@ int sn_conv_bank_prepared(const void* x, int x_dtype, const float* bank, const f
  * sn_conv_prep_verdict_offset() of each group's blob, written by every walk launch; it depends on the weights, the
  * coefficients, the tolerance and on which outputs are asked for, on nothing else.  A caller that has READ it as 0 for
  * exactly these (e.g. a serving loop whose parameters do not change: read it back once, asynchronously) may use this entry:
- * the ~3 us empty dispatch of the fallback launch disappears.  If the verdict is not 0 the outputs are NOT written (the
- * verdict still is): only for callers that checked. */
+ * the ~3 us empty dispatch of the fallback launch disappears.  If the verdict is NOT 0 -- the caller's knowledge was stale --
+ * the launch fills `out` / `act` with NaN and latches the sticky device status (code 2, sn_device_status): the call itself
+ * has returned SN_OK by then (it is asynchronous), the NEXT sn_* call on the device fails with SN_ERR_DEVICE_STATUS.  It
+ * never leaves the outputs unwritten. */
 int sn_conv_bank_prepared_served(const void* x, int x_dtype, const float* bank, const float* lambdas, void* prep,
                                  int B, int Z, int X, int Y, int G, int kz, int kx, int ky,
                                  void* act, void* out, int out_dtype, sn_stream_t stream);
 int sn_conv_prep_verdict_offset(void);
-/* Diagnostics: how many waves of the int8 kernels ever gave up a bounded LDS hand-over spin (must stay 0: a non-zero
- * count means a launch may have read a ring slot that had not landed).  Synchronises the device. */
+/* Diagnostics: how many waves of the int8 kernels ever gave up a bounded LDS hand-over spin (must stay 0).  A give-up is
+ * not silent: it latches the sticky device status (code 1 / 3, above), and the z-walk overwrites its workgroup's outputs
+ * with NaN.  Synchronises the device. */
 int sn_conv_i8_spin_timeouts(unsigned long long* count);
 
 /* The same forward output through linearity, without materialising the bank activations:

@@ -28,6 +28,8 @@ _P, _I = c_void_p, c_int
 SYMBOLS = {
     "sn_version": (c_int, []),
     "sn_prepare_device": (c_int, []),
+    "sn_device_status": (c_int, [_P, _P]),
+    "sn_device_status_clear": (c_int, []),
     "sn_last_error": (c_char_p, []),
     "sn_device_count": (c_int, []),
     "sn_conv_i8_path_counts": (c_int, [_P]),
@@ -121,6 +123,28 @@ def load() -> ctypes.CDLL:
 
 
 def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sn_last_error()
+        raise HipLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def device_status() -> Tuple[int, int, int]:
+    """(code, workgroup, detail) of the current device's sticky status (sn_device_status): code 0 = healthy; 1 a dependency
+    spin of the z-walk gave up, 2 a launch made with `assume_served` was declined by its bank's guard, 3 a tile kernel's
+    hand-over spin gave up.  While a code is latched every launching entry of the library raises.  A host memory read: no
+    synchronisation -- a kernel that is still running may latch later."""
+    code = ctypes.c_int(0)
+    detail = (ctypes.c_int * 2)(0, 0)
+    _check_plain(load().sn_device_status(ctypes.byref(code), detail), "sn_device_status")
+    return int(code.value), int(detail[0]), int(detail[1])
+
+
+def device_status_clear() -> None:
+    """Synchronises the device and re-arms its sticky status (sn_device_status_clear)."""
+    _check_plain(load().sn_device_status_clear(), "sn_device_status_clear")
+
+
+def _check_plain(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().sn_last_error()
         raise HipLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
@@ -299,7 +323,11 @@ class PreparedVerdict:
     are served by the z-walk, so that later launches of the same combination can leave the fallback launch out
     (sn_conv_bank_prepared_served).  After a launch made with the fallback in place, `note(prep, key)` enqueues a 4-byte
     copy of the verdict words into pinned host memory and records an event; `served(key)` is True once that copy has
-    completed and read 0 -- until then (and for every new key: an optimiser step changes it) the caller keeps the fallback."""
+    completed and read 0 -- until then (and for every new key: an optimiser step changes it) the caller keeps the fallback.
+    The words start every preparation at -1 (conv_prep.h): a 0 can only have been written by a walk that ran on THIS bank,
+    and a -1 that comes back (the noted call was not the walk's) teaches nothing.  A caller whose knowledge is stale anyway
+    -- the one thing the key cannot see is a raw-pointer write -- gets NaN outputs and the sticky device status from the
+    launch itself (sn_conv_bank_prepared_served), never an unwritten buffer."""
 
     def __init__(self):
         self._key = None
@@ -318,7 +346,12 @@ class PreparedVerdict:
             self._key, self._state = key, 0
             return False
         if self._state == 1 and self._event.query():
-            self._state = 2 if int(self._host.abs().max()) == 0 else 3
+            # -1: the preparation's sentinel -- no walk has written a verdict for this bank (the call that was noted went to
+            # other kernels: a shape the walk does not serve): nothing learnt, the next call is noted again
+            if int(self._host.min()) < 0:
+                self._state = 0
+            else:
+                self._state = 2 if int(self._host.max()) == 0 else 3
         return self._state == 2
 
     def note(self, prep: torch.Tensor, key) -> None:

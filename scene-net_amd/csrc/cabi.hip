@@ -25,6 +25,8 @@ int option_conv_i8_legacy() {
     }
     return v;
 }
+static std::atomic<int> g_i8z_fault{0};
+int option_conv_i8z_inject_fault() { return g_i8z_fault.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8z_variant{2};
 int option_conv_i8z_variant() { return g_i8z_variant.load(std::memory_order_relaxed); }
 static std::atomic<int> g_corr_tile_bytes{0};
@@ -99,6 +101,11 @@ constexpr int kFlagRing = 1024, kFlagCapture = 4096, kFlagMaxDev = 16;
 std::mutex g_flag_mu;
 int32_t* g_flag_mem[kFlagMaxDev] = {nullptr};
 unsigned g_flag_next[kFlagMaxDev] = {0}, g_flag_cap_next[kFlagMaxDev] = {0};
+// The sticky status words of a device (common.h): 16 ints of pinned, device-mapped host memory, allocated with the flag pool
+// (so the same rule holds: before the first stream capture).  Kernels latch into them with system-scope atomics; the host
+// reads them at every launch check.  Never freed: a captured graph keeps the device pointer.
+volatile int32_t* g_sticky_host[kFlagMaxDev] = {nullptr};
+int32_t* g_sticky_dev[kFlagMaxDev] = {nullptr};
 int32_t* flag_pool_locked(int dev) {
     if (!g_flag_mem[dev]) {
         if (hipMalloc((void**)&g_flag_mem[dev], (kFlagRing + kFlagCapture) * sizeof(int32_t)) != hipSuccess) {
@@ -108,9 +115,47 @@ int32_t* flag_pool_locked(int dev) {
         }
         (void)hipMemset(g_flag_mem[dev], 0, (kFlagRing + kFlagCapture) * sizeof(int32_t));
     }
+    if (!g_sticky_host[dev]) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 16 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+            hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, 16 * sizeof(int32_t));
+            g_sticky_dev[dev] = static_cast<int32_t*>(d);
+            g_sticky_host[dev] = static_cast<volatile int32_t*>(h);
+        } else {
+            (void)hipGetLastError();   // no sticky words: kernels skip the latch (nullptr), the counters still count
+        }
+    }
     return g_flag_mem[dev];
 }
 }  // namespace
+
+int32_t* sticky_device_ptr() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kFlagMaxDev) return nullptr;
+    if (g_sticky_dev[dev]) return g_sticky_dev[dev];   // (set once, never changed: no lock on the launch path)
+    std::lock_guard<std::mutex> lock(g_flag_mu);
+    (void)flag_pool_locked(dev);
+    return g_sticky_dev[dev];
+}
+
+int sticky_check(const char* what) {
+    // every device this process has touched: a latched status is a property of the process's results, not of one stream
+    for (int dev = 0; dev < kFlagMaxDev; ++dev) {
+        volatile int32_t* w = g_sticky_host[dev];
+        if (!w || w[0] == 0) continue;
+        static const char* const kText[] = {"", "a dependency spin of the z-walk contraction gave up (its workgroup's outputs are NaN)",
+                                            "a launch made with `assume served` was declined by the bank's guard (its outputs are NaN): "
+                                            "a cached verdict did not belong to these parameters",
+                                            "a hand-over spin of an int8 tile kernel gave up (that launch's output is not to be trusted)"};
+        const int code = w[0];
+        return fail(SN_ERR_DEVICE_STATUS, "%s: device %d has a latched status %d -- %s [workgroup %d, detail %d]; "
+                    "sn_device_status_clear() re-arms the device", what, dev, code,
+                    (code >= 1 && code <= 3) ? kText[code] : "unknown", (int)w[2], (int)w[3]);
+    }
+    return SN_OK;
+}
 
 int32_t* device_flag_slot(hipStream_t stream) {
     int dev = 0;
@@ -159,6 +204,10 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_i8_fold.store(value ? 1 : 0, std::memory_order_relaxed);
         return SN_OK;
     }
+    if (strcmp(name, "conv_i8z_inject_fault") == 0) {
+        sn::g_i8z_fault.store(value ? 1 : 0, std::memory_order_relaxed);
+        return SN_OK;
+    }
     if (strcmp(name, "conv_i8z_variant") == 0) {
         if (value < 0 || value > 2) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: conv_i8z_variant is 0, 1 or 2");
         sn::g_i8z_variant.store(value, std::memory_order_relaxed);
@@ -184,6 +233,7 @@ extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_i8_legacy") == 0) return sn::option_conv_i8_legacy();
     if (name && strcmp(name, "conv_i8_fold") == 0) return sn::option_conv_i8_fold();
     if (name && strcmp(name, "conv_i8z_variant") == 0) return sn::option_conv_i8z_variant();
+    if (name && strcmp(name, "conv_i8z_inject_fault") == 0) return sn::option_conv_i8z_inject_fault();
     if (name && strcmp(name, "corr_sparse_tile_bytes") == 0) return sn::option_corr_sparse_tile_bytes();
     if (name)
         for (int i = 0; i < sn::kOptCount; ++i)
@@ -199,7 +249,37 @@ extern "C" int sn_prepare_device(void) {
     return sn::flag_pool_locked(dev) ? SN_OK : sn::fail(SN_ERR_LAUNCH, "sn_prepare_device: cannot allocate the flag pool");
 }
 
-extern "C" int sn_version(void) { return 102; }   // 102: round-3 entries (riders, sn_conv_corr_ws, sn_conv_fused_v, sn_loss_*_m / _u)
+extern "C" int sn_device_status(int* code, int* detail2) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= sn::kFlagMaxDev)
+        return sn::fail(SN_ERR_NO_DEVICE, "sn_device_status: no current HIP device");
+    volatile int32_t* w = sn::g_sticky_host[dev];
+    if (code) *code = w ? (int)w[0] : 0;
+    if (detail2) {
+        detail2[0] = w ? (int)w[2] : 0;
+        detail2[1] = w ? (int)w[3] : 0;
+    }
+    return SN_OK;
+}
+
+extern "C" int sn_device_status_clear(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= sn::kFlagMaxDev)
+        return sn::fail(SN_ERR_NO_DEVICE, "sn_device_status_clear: no current HIP device");
+    // the kernels that latched have to be through before the words are re-armed
+    if (hipDeviceSynchronize() != hipSuccess) {
+        const hipError_t e = hipGetLastError();
+        return sn::fail(SN_ERR_LAUNCH, "sn_device_status_clear: %s", hipGetErrorString(e));
+    }
+    volatile int32_t* w = sn::g_sticky_host[dev];
+    if (w) {
+        w[0] = 0; w[2] = 0; w[3] = 0;
+        w[1] = 0;
+    }
+    return SN_OK;
+}
+
+extern "C" int sn_version(void) { return 103; }   // 103: round 4 (sticky device status); 102: round-3 entries (riders, sn_conv_corr_ws, sn_conv_fused_v, sn_loss_*_m / _u)
 
 extern "C" const char* sn_last_error(void) { return sn::error_buffer(); }
 

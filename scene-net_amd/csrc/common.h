@@ -18,16 +18,19 @@ inline int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+int sticky_check(const char* what);   // below / cabi.hip
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
-    return SN_OK;
+    return sticky_check(what);   // (a host read of pinned words; SN_OK unless a kernel has latched a status)
 }
 
 inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 int option_conv_i8_fold();            // cabi.hip (sn_set_option "conv_i8_fold", default 1): 0 = never try the folded int8 kernel (conv_i8s.hip)
+int option_conv_i8z_inject_fault();   // cabi.hip (sn_set_option "conv_i8z_inject_fault"): test hook, see conv_i8z.inc's prologue
 int option_conv_i8z_variant();        // cabi.hip (sn_set_option "conv_i8z_variant"): shape of the z-walk kernel's rounds (conv_i8z.inc)
 int option_corr_sparse_tile_bytes();  // cabi.hip (sn_set_option "corr_sparse_tile_bytes"): input bytes per job of the sparse correlation (0: 2048, the maximum)
 int option_conv_i8_legacy();          // cabi.hip (sn_set_option "conv_i8_legacy"): 1 = the four-copy kernel of conv_i8.hip for every shape
@@ -82,6 +85,28 @@ inline int debug_env_int(const char* name) {
     (void)name;
     return 0;
 #endif
+}
+
+// ---- sticky device status (round 4): a kernel that cannot keep its contract (a dependency spin that gave up, a launch
+// made with `assume served` whose bank the guard declines) must not return plausible numbers.  It poisons what it owns
+// (NaN) and LATCHES a status in four host-pinned words per device; every sn_* launch path looks at them (check_launch,
+// a host memory read: no synchronisation) and fails with SN_ERR_DEVICE_STATUS until sn_device_status_clear().
+//   words: [0] code (0: healthy)  [1] claim (first reporter wins)  [2], [3] detail (workgroup, ticket / verdict)
+//   codes: 1 a dependency spin of the z-walk gave up;  2 a `served` launch of the z-walk declined its bank;
+//          3 a tile kernel's (folded / stride-4 / four-copy) spin gave up
+int32_t* sticky_device_ptr();   // cabi.hip: the current device's words as a DEVICE pointer (nullptr: pool not allocated)
+int sticky_check(const char* what);   // cabi.hip: SN_OK, or SN_ERR_DEVICE_STATUS with the latched code in the error text
+__device__ __forceinline__ void sticky_latch(int32_t* sticky, int code, int a, int b) {
+    if (!sticky) return;
+    // (a, b are wave-uniform; made opaque HERE so that hipcc does not materialise them in vector registers ahead of the hot
+    // loop the latch sits behind -- [measured in the ISA] it hoisted a v_mov of blockIdx.x out of the z-walk's ticket loop and
+    // spilled it: the kernel's only scratch use)
+    asm volatile("" : "+s"(a), "+s"(b));
+    if (__hip_atomic_exchange(&sticky[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        __hip_atomic_store(&sticky[2], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&sticky[3], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&sticky[0], code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 float option_conv_i8_tolerance();   // cabi.hip (sn_set_option "conv_i8_tolerance_ppb"): 0 = quantisation guard off

@@ -101,6 +101,7 @@ struct Shape {
     int stagger;           // s_sleep units (64 clocks) waves 4-7 wait once before their first round
     int dynamic;           // rounds of a tile are claimed from an LDS ticket counter (else dealt: wave, wave + 8, ...)
     int dbg;
+    int32_t* sticky;       // the device's sticky status words (common.h): a spin that gives up latches code 3
     RowPlan plan;
     FoldPlan fplan;        // conv_occ_i8f_kernel only
 };
@@ -909,7 +910,10 @@ __device__ __forceinline__ bool conv_occ_i8s_body(const uint8_t* __restrict__ x,
         SN_WT(5, t_e);
         SN_WT(6, t_tile);
     }
-    if (!healthy && lane == 0) atomicAdd(&g_fold_counts[3], 1ull);   // reported: sn_conv_i8_spin_timeouts
+    if (!healthy && lane == 0) {   // a halo hand-over never arrived: this launch's output cannot be trusted -- loud
+        atomicAdd(&g_fold_counts[3], 1ull);   // (sn_conv_i8_spin_timeouts)
+        sn::sticky_latch(s.sticky, 3, (int)blockIdx.x, 0);
+    }
     SN_ST(5);
     return false;
 }
@@ -1270,7 +1274,10 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8f_kernel(const uint8_t* _
             wave_signal(&landed[(it + 2) % kNB], lane);
         }
     }
-    if (!healthy && lane == 0) atomicAdd(&g_fold_counts[3], 1ull);   // reported: sn_conv_i8_spin_timeouts
+    if (!healthy && lane == 0) {   // a halo hand-over never arrived: this launch's output cannot be trusted -- loud
+        atomicAdd(&g_fold_counts[3], 1ull);   // (sn_conv_i8_spin_timeouts)
+        sn::sticky_latch(s.sticky, 3, (int)blockIdx.x, 0);
+    }
     SN_ST(5);
 }
 
@@ -1409,6 +1416,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx;
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
     s.gate = sn::current_gate();
+    s.sticky = sn::sticky_device_ptr();
     s.nyt = (Y + TY - 1) / TY;
     // wrong-result / timing switches: -DSN_CONV_DEBUG builds only (common.h); 0 in the product
     s.dbg = sn::debug_env_int("SN_CONV_I8_DBG");
@@ -1518,6 +1526,10 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     z.gate = s4.gate;
     z.tol = s4.tol;
     z.route = route;
+    z.dbg = sn::option_conv_i8z_inject_fault() ? 1 : 0;
+    z.served = assume_served ? 1 : 0;
+    z.sticky = sn::sticky_device_ptr();
+    s4.sticky = z.sticky;
     z.nxt = (X + kZTX - 1) / kZTX;
     z.nyt = (Y + TY - 1) / TY;
     const long long ncol = (long long)B * z.nxt * z.nyt;

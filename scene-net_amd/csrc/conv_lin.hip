@@ -146,10 +146,22 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     // the first tile's halo is requested first and travels meanwhile ([measured] the bank loads ahead of it instead: the
     // prologue got 0.6 us longer -- the halo's 16 loads then queue behind 48 others)
     if ((int)blockIdx.x < s.ntiles) halo_issue(blockIdx.x);
+    // The guard declined and NOBODY is enqueued behind this launch (the caller assumed "served" from a verdict that does not
+    // belong to these tables -- a stale cache): every workgroup takes the same decision, so together they fill `out` with
+    // NaN, and the sticky status is latched.  Loud, not quiet (round 4; the z-walk does the same, conv_i8z.inc).
+    auto declined_unserved = [&]() {
+        const OT nan = (OT)__int_as_float(0x7fc00000);
+        const size_t n = (size_t)s.B * V;
+        for (size_t i = (size_t)blockIdx.x * kThreads + tid; i < n; i += (size_t)gridDim.x * kThreads) out[i] = nan;
+        if (tid == 0 && blockIdx.x == 0) sn::sticky_latch(s.sticky, 2, 0, 1);
+    };
     if (s.prep) {
         const LinBlob lb = lin_blob_layout(s.nsteps, kW24);
         const int32_t verdict = *reinterpret_cast<const int32_t*>(s.prep + lb.tail_off + 4);
-        if (verdict != 0 && s.tol > 0.0f) return;   // the bound was over the tolerance: the gated fp32 launches behind take over
+        if (verdict != 0 && s.tol > 0.0f) {   // the bound was over the tolerance: the gated fp32 launches behind take over
+            if (s.served) declined_unserved();
+            return;
+        }
         const uint4* src = reinterpret_cast<const uint4*>(s.prep);
         for (int i = tid; i < (s.nsteps + 1) * 3 * 64; i += kThreads) At[i] = src[i];
         if constexpr (kW24) {
@@ -158,7 +170,10 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         }
         if (tid == 0) misc[0] = *reinterpret_cast<const float*>(s.prep + lb.tail_off);
     } else {
-        if (lin_tables<kW24>(bank, lambdas, s, At, offtab, misc, misc, kstar, s.route, blockIdx.x == 0)) return;
+        if (lin_tables<kW24>(bank, lambdas, s, At, offtab, misc, misc, kstar, s.route, blockIdx.x == 0)) {
+            if (s.served) declined_unserved();
+            return;
+        }
     }
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
     const float scale = misc[0];
@@ -415,6 +430,8 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     if (out_dtype == SN_BF16) s.tol = 0.0f;   // bf16 storage rounds at 2^-9: the 24-bit fixed point is not what limits it
     s.route = nullptr;
     s.prep = static_cast<const uint8_t*>(prep);
+    s.served = assume_served ? 1 : 0;
+    s.sticky = sn::sticky_device_ptr();
     if (prep) {
         // the verdict was written with the tables (at the tolerance in force then): the gated launches read it there
         s.route = s.tol > 0.0f ? reinterpret_cast<int32_t*>(const_cast<uint8_t*>(s.prep) + lin_blob_layout(s.nsteps, w24).tail_off + 4)

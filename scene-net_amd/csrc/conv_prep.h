@@ -30,6 +30,7 @@ constexpr int kPrepFit = 12544;                // int [16]           1: every pa
 constexpr int kPrepMagic = 12608;              // int                0x5a57414c once written
 constexpr int kPrepZero = 12800;               // 16 zero bytes (the z-walk's LDS-DMA source for pieces outside the grid)
 constexpr int kPrepRoute = 12672;              // int                the caller-owned route flag of the launches using this blob
+                                               //                    (-1 fresh from the preparation; 0 / 1 / 2 a walk's verdict)
 static_assert(kPrepRoute + 4 <= kPrepZero && kPrepZero + 16 <= SN_CONV_PREP_BYTES && kPrepZero % 16 == 0, "blob layout");
 
 // slot -> folded kernel row of lane group qq (the z-walk plan; regular slots as FoldPlan: planes dz = 2 qq + a)
@@ -160,6 +161,10 @@ __device__ __forceinline__ void prep_one_kernel(float* w, int* asym_s, bool vali
         if (g == 0) {
             *reinterpret_cast<int*>(prep + kPrepMagic) = 0x5a57414c;
             *reinterpret_cast<uint4*>(prep + kPrepZero) = make_uint4(0u, 0u, 0u, 0u);
+            // the verdict word starts every preparation as "no walk has decided on THIS bank yet" (-1): a caller that learns
+            // verdicts by reading the word back (PreparedVerdict) can then never take the previous bank's 0 -- or the zero a
+            // fresh buffer holds -- for this bank's, e.g. after a call whose shape the walk does not serve
+            *reinterpret_cast<int*>(prep + kPrepRoute) = -1;
         }
     }
 }

@@ -21,6 +21,49 @@ _SLOT_OF = {"radius": _hip.SN_P_RADIUS, "sigma": _hip.SN_P_SIGMA, "apex": _hip.S
             "cone_radius": _hip.SN_P_CONE_RADIUS, "cone_inc": _hip.SN_P_CONE_INC, "neg_factor": _hip.SN_P_NEG_FACTOR}
 
 
+# ---- writes that no `_version` sees
+# Everything this module keeps between calls (packed parameters, effective coefficients, K3L's tables, learnt guard verdicts)
+# is keyed on each parameter's identity and `_version`.  Every in-place op and every re-assignment moves those -- a write
+# through `.data` does not (`p.data` is a fresh tensor with its own version counter).  So the model's parameters are
+# instances of a Parameter subclass whose `.data` property counts its uses: `p.data.fill_(..)`, `p.data = t`, an old-style
+# `p.data.add_(-lr * g)` all pass through the getter or the setter, the counter is part of every cache key, and the next
+# forward rebuilds what it kept.  (A READ through `.data` -- the reference's own `val.data.item()` in its logging -- also
+# counts: a spurious rebuild costs microseconds.)  Not caught: a tensor obtained from `.data` EARLIER and written to later;
+# a write through a raw pointer (CapturedTrainingStep.replay() calls invalidate_caches() itself).  `invalidate_caches()` is
+# the explicit form.  The counter is global on purpose: nothing has to be attached to a parameter, so deepcopy / pickle /
+# load_state_dict keep working, and a Parameter that lost the subclass on the way (pickle restores a plain nn.Parameter) is
+# re-tagged the next time the keys are built.
+_DATA_TOUCHES = [0]
+_TENSOR_DATA = torch.Tensor.data
+
+
+class _TrackedParameter(nn.Parameter):
+    @property
+    def data(self):
+        _DATA_TOUCHES[0] += 1
+        return _TENSOR_DATA.__get__(self)
+
+    @data.setter
+    def data(self, value):
+        _DATA_TOUCHES[0] += 1
+        _TENSOR_DATA.__set__(self, value)
+
+    def __repr__(self):
+        return nn.Parameter.__repr__(self.as_subclass(nn.Parameter))   # prints like the nn.Parameter it stands for
+
+
+def _track(p):
+    """tags a Parameter so that its `.data` accesses are counted (a class swap: same object, same storage)"""
+    if type(p) is nn.Parameter:
+        p.__class__ = _TrackedParameter
+    return p
+
+
+def _set_data_untracked(p, value) -> None:
+    """p.data = value from inside this module (the flat buffer's aliasing): not a user write"""
+    _TENSOR_DATA.__set__(p, value)
+
+
 class _LivePack:
     """The packed-parameter tensor P of the latest differentiable forward.  The criteria (criterions.py) take their
     penalties from P, so every scalar receives ONE gradient from ONE autograd node instead of being stacked again and
@@ -162,8 +205,9 @@ class SceneNet(nn.Module):
     def invalidate_caches(self) -> None:
         """Drops everything derived from the parameters that is kept between calls (packed parameters, effective
         coefficients, the fused forward's tables, the learnt guard verdicts).  The caches key on each parameter's identity
-        and `_version`, which every in-place op and every re-assignment changes -- but a write through `.data` (or through
-        a raw pointer) does not: call this after such a write."""
+        and `_version` (every in-place op, every re-assignment) and on the count of `.data` accesses (_TrackedParameter: a
+        write through `.data` is seen too).  What is left for this call: a write through a raw pointer -- a replayed
+        optimiser graph (CapturedTrainingStep.replay() calls it) -- or through a `.data` tensor taken earlier."""
         self._pack_cache = None
         self._lambda_cache = None
         for k in ("_fused_state", "_prepared_verdict", "_geneo_params_cache"):
@@ -218,7 +262,7 @@ class SceneNet(nn.Module):
         """([G, SN_NPARAM] f32, [G] i32) on `device`; re-packed only when a parameter changed."""
         # (the key walks the plain dicts behind ModuleDict / ParameterDict: through their public iterators this one line
         # cost ~30 us of the eager step's ~150 us of host time)
-        key = (device,) + tuple((id(p), p._version) for p in self._geneo_leaves())
+        key = (device, _DATA_TOUCHES[0]) + tuple((id(_track(p)), p._version) for p in self._geneo_leaves())
         if self._pack_cache is not None and self._pack_cache[0] == key:
             return self._pack_cache[1], self._pack_cache[2]
         rows, kinds = [], []
@@ -244,14 +288,16 @@ class SceneNet(nn.Module):
         reference's side effect of re-creating lambdas_dict[last_lambda] (SCENE_Net.py:333)."""
         # ~17 tiny dependent device ops: redone only when a coefficient (or last_lambda) changed since the last
         # call -- 1 - sum(others) is then already what lambdas_dict[last_lambda] holds.
-        key = (device, self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict._parameters.values())
+        key = (device, self.last_lambda, _DATA_TOUCHES[0]) + tuple((id(_track(p)), p._version)
+                                                                  for p in self.lambdas_dict._parameters.values())
         if self._lambda_cache is not None and self._lambda_cache[0] == key:
             return self._lambda_cache[1]
         last = 1 - sum(self.lambdas_dict.values()) + self.lambdas_dict[self.last_lambda]
         self.lambdas_dict[self.last_lambda] = nn.Parameter(last.detach(), requires_grad=False)
         vals = [self.lambdas_dict[f"lambda_{g}"].detach() for g in self.geneos]
         lam = torch.stack(vals).to(device=device, dtype=torch.float32).contiguous()
-        key = (device, self.last_lambda) + tuple((id(p), p._version) for p in self.lambdas_dict._parameters.values())
+        key = (device, self.last_lambda, _DATA_TOUCHES[0]) + tuple((id(_track(p)), p._version)
+                                                                  for p in self.lambdas_dict._parameters.values())
         self._lambda_cache = (key, lam)
         return lam
 
@@ -404,7 +450,7 @@ class SceneNet(nn.Module):
         slots = torch.tensor([i for _, i in leaves], dtype=torch.int64, device=device)
         flat[slots] = vals
         for p, i in leaves:
-            p.data = flat[i]
+            _set_data_untracked(p, flat[i])
         names = list(self.geneos)
         order = sorted(range(G), key=lambda i: f"lambda_{names[i]}")  # nn.ParameterDict order (sorted names)
         last = names.index(self.last_lambda.replace("lambda_", "", 1))
@@ -477,6 +523,13 @@ class _GeneoForwardFn(torch.autograd.Function):
         p = flat[:n].view(G, _hip.SN_NPARAM)
         if bank_lam is not None:   # (SceneNet.train_rider: the same kernels' code ran in the voxelisation's first launch)
             bank, lam = bank_lam
+            if not torch.cuda.is_current_stream_capturing():
+                # the rider's buffers are the model's persistent ones, rewritten in place by the NEXT rider launch through a
+                # raw pointer (no version bump, so autograd's saved-tensor check cannot see it): a second forward before this
+                # graph's backward -- gradient accumulation, retain_graph, an eval pass with grad enabled -- would make the
+                # backward read the other step's bank.  Eagerly the step keeps its own copy (46 KB + G floats); a captured
+                # step is forward -> backward inside one graph and needs none.
+                bank, lam = bank.clone(), lam.clone()
         else:
             bank, lam = _hip.geneo_bank_lambdas(p, meta["kinds"], kernel_size, flat[n:], meta["order"], meta["last"])
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32

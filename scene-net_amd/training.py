@@ -142,4 +142,8 @@ class CapturedTrainingStep:
         if self.graph_opt is not None:
             self._exchange()
             self.graph_opt.replay()
+        # the replayed optimiser step writes the parameters through the addresses baked into the graph: no tensor's `_version`
+        # moves, and the model's parameter-derived caches (packed parameters, coefficients, K3L tables, learnt verdicts) key on
+        # those versions -- a validation forward between replays would run on the previous weights
+        self.pipe.model.invalidate_caches()
         return self.loss

@@ -3,9 +3,12 @@ contraction as sn_conv_bank (SceneNet.forward, core/models/SCENE_Net.py:322-339)
 sn_conv_bank_prep.  Same integers, same head: the result must equal sn_conv_bank's bit for bit on every shape, and meet
 the fp64 oracle within 1e-4.
 
-Transitivity note: at the full C2 batch the z-walk, folded, stride-4 and four-copy kernels are compared
-with each other bit for bit; the fp64 oracle is met directly at <= 2 tiles of 64^3 (seconds on the CPU), and on the full
-batch through that chain of equalities."""
+The fp64 oracle (oracle/geneo_oracle.py: scenenet_forward, pinned to the reference's golden forwards) is met DIRECTLY on every
+small shape, on tiles 0 and 31 of the full C2 batch and on one tile of C3's per-GPU share (32 x 128^3) -- no chain of
+kernel-vs-kernel equalities in between (missing 2); the kernels are compared with each other bit for bit on top.
+
+Round 4: the loud failure path (a dependency spin that gives up, a `served` launch whose bank the guard declines: NaN outputs +
+the sticky device status) is tested on the product build through sn_set_option("conv_i8z_inject_fault")."""
 import numpy as np
 import pytest
 import torch
@@ -92,6 +95,11 @@ def test_zwalk_full_c2_batch_and_128_cubed(hip_device):
     assert _delta(c0, _hip.conv_i8_path_counts()) == (2, 0, 0)
     assert torch.equal(o_z, o_r)
     assert float(o_z.max()) > 0.05     # not a trivial all-zero comparison
+    # the fp64 oracle inside the full batch, directly: its first and its last tile (SCENE_Net.py:322-339 restated)
+    for t in (0, 31):
+        ref = go.scenenet_forward(occ[t:t + 1].cpu().double(), specs, (9, 9, 9), lambdas, last, names=names)
+        assert (o_z[t:t + 1].cpu().double() - ref).abs().max().item() < TOL, t
+        assert float(ref.max()) > 0.05
     occ128 = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles[:2], device=hip_device), (128,) * 3,
                                 occ_dtype=torch.bool).occ
     (a_z, o_z), (a_r, o_r) = _both(occ128, bank, lam, want_act=True)
@@ -335,14 +343,7 @@ def test_verdict_is_learnt_without_a_sync_and_the_fallback_launch_left_out(hip_d
     torch.cuda.synchronize()
     assert _hip.prep_verdicts(prep).cpu().tolist() == [1]
     assert torch.equal(out, _hip.conv_bank(occ.view(torch.uint8), wide, lam)[1])
-    # what a caller who assumed wrongly would see: the verdict, and nothing written
-    canary = torch.full_like(out, -7.0)
-    load = _hip.load()
-    rc = load.sn_conv_bank_prepared_served(occ.data_ptr(), _hip.SN_OCC8, wide.data_ptr(), lam.data_ptr(), prep.data_ptr(),
-                                           2, 64, 64, 64, 16, 9, 9, 9, None, canary.data_ptr(), _hip.SN_F32,
-                                           torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert rc == 0 and _hip.prep_verdicts(prep).cpu().tolist() == [1] and bool((canary == -7.0).all())
+    # what a caller who assumed wrongly gets: test_served_launch_on_a_declined_bank_is_loud (below)
 
 
 def test_fused_forward_learns_its_verdict_and_drops_the_gated_launches(hip_device):
@@ -419,3 +420,173 @@ def test_fused_forward_on_prepared_tables(hip_device, ks):
         assert torch.equal(got, _hip.conv_bank(x.view(torch.uint8), bank, lam, want_act=False, want_out=True)[1])
     finally:
         _hip.set_option("conv_i8_tolerance_ppb", 90000)
+
+
+# ---------------------------------------------------------------------------------------------- round 4: loud, not quiet
+def _expect_latched(code):
+    """the sticky status is latched with `code`, every launching entry now fails, and clearing re-arms the device"""
+    torch.cuda.synchronize()
+    st = _hip.device_status()
+    assert st[0] == code, st
+    with pytest.raises(_hip.HipLibraryError, match="latched status"):
+        _hip.conv_bank_prep(torch.zeros((16, 9, 9, 9), device="cuda"))
+    _hip.device_status_clear()
+    assert _hip.device_status()[0] == 0
+
+
+def test_spin_give_up_is_loud(hip_device):
+    """A dependency that never arrives (injected: plane 0's first raw rows are never reported as landed): the walk does not
+    return numbers computed from a ring slot that was not ready -- every workgroup overwrites what it owns with NaN, the
+    device's sticky status is latched (code 1) and the next sn_* call fails until the status is cleared."""
+    torch.manual_seed(11)
+    occ = (torch.rand((2, 1, 16, 24, 64)) < 0.3).to(hip_device)
+    bank = _symmetric_bank(16, 5).to(hip_device)
+    lam = ((torch.rand(16) - 0.3) / 16).to(hip_device)
+    prep = _hip.conv_bank_prep(bank)
+    good_a, good_o = _hip.conv_bank(occ, bank, lam, want_act=True, want_out=True, prep=prep)
+    t0 = _hip.conv_i8_spin_timeouts()
+    assert _hip.device_status()[0] == 0
+    _hip.set_option("conv_i8z_inject_fault", 1)
+    try:
+        # (the call itself returns: the kernel is asynchronous and nothing was latched when it was enqueued)
+        act, out = _hip.conv_bank(occ, bank, lam, want_act=True, want_out=True, prep=prep)
+    finally:
+        _hip.set_option("conv_i8z_inject_fault", 0)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all()) and bool(torch.isnan(act).all())
+    _expect_latched(1)
+    assert _hip.conv_i8_spin_timeouts() > t0
+    # re-armed: the same call is served again, same bits as before the fault
+    act2, out2 = _hip.conv_bank(occ, bank, lam, want_act=True, want_out=True, prep=prep)
+    torch.cuda.synchronize()
+    assert torch.equal(act2, good_a) and torch.equal(out2, good_o) and _hip.device_status()[0] == 0
+
+
+def test_served_launch_on_a_declined_bank_is_loud(hip_device):
+    """sn_conv_bank_prepared_served leaves the fallback launch out on the caller's word that the verdict is "served".  When
+    that word is wrong -- a bank over the quantisation tolerance, a bank that is not symmetric -- the outputs are NaN and
+    the sticky status says so (code 2); they are never left unwritten."""
+    torch.manual_seed(12)
+    occ = (torch.rand((2, 1, 16, 16, 64)) < 0.3).to(hip_device)
+    lam = ((torch.rand(16) - 0.3) / 16).to(hip_device)
+    wide = _symmetric_bank(16, 3, scale=torch.full((16,), 40.0)).to(hip_device)
+    asym = _symmetric_bank(16, 4)
+    asym[3, 2, 1, 7] += 0.125
+    for bank, verdict in ((wide, 1), (asym.to(hip_device), 2)):
+        prep = _hip.conv_bank_prep(bank)
+        assert _hip.prep_verdicts(prep).cpu().tolist() == [-1]          # fresh from the preparation: no verdict yet
+        out = torch.full((2, 1, 16, 16, 64), -7.0, device=hip_device)
+        rc = _hip.load().sn_conv_bank_prepared_served(occ.data_ptr(), _hip.SN_OCC8, bank.data_ptr(), lam.data_ptr(),
+                                                      prep.data_ptr(), 2, 16, 16, 64, 16, 9, 9, 9, None, out.data_ptr(),
+                                                      _hip.SN_F32, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and _hip.prep_verdicts(prep).cpu().tolist() == [verdict]
+        assert bool(torch.isnan(out).all())
+        _expect_latched(2)
+        # with the fallback in place the same blob gives the other kernels' result
+        ok = _hip.conv_bank(occ, bank, lam, prep=prep)[1]
+        assert torch.equal(ok, _hip.conv_bank(occ, bank, lam)[1]) and not bool(torch.isnan(ok).any())
+    assert _hip.device_status()[0] == 0
+
+
+def test_fused_forward_assumed_served_on_a_declined_bank_is_loud(hip_device):
+    """the same contract for the forward through linearity (sn_conv_fused_prepared with assume_served)"""
+    model = _bench_model(hip_device)
+    x = (torch.rand(2, 1, 32, 32, 64, device=hip_device) < 0.05)
+    bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+    blob = torch.empty(_hip.conv_fused_prep_bytes((9, 9, 9)), dtype=torch.uint8, device=hip_device)
+    _hip.set_option("conv_i8_tolerance_ppb", 1)      # a tolerance nothing meets: the blob's verdict is 1
+    try:
+        _hip.conv_fused_prep(bank, lam, blob)
+        out = _hip.conv_fused(x, bank, lam, out_dtype=torch.float32, prep=blob, assume_served=True)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out).all())
+        _expect_latched(2)
+        kept = _hip.conv_fused(x, bank, lam, out_dtype=torch.float32, prep=blob, assume_served=False)
+        assert torch.equal(kept, _hip.conv_bank(x.view(torch.uint8), bank, lam, want_act=False, want_out=True)[1])
+    finally:
+        _hip.set_option("conv_i8_tolerance_ppb", 90000)
+    assert _hip.device_status()[0] == 0
+
+
+def test_a_verdict_is_never_learnt_from_a_call_the_walk_did_not_serve(hip_device):
+    """parameters whose bank is over the tolerance, a first call on a grid the walk does not serve (Y % 16 != 0:
+    the verdict word is not rewritten), then a 64^3 grid.  The preparation resets the word to -1, so the read-back of the
+    first call teaches nothing, the second call keeps its fallback, and the result is sn_conv_bank's."""
+    model = _bench_model(hip_device)
+    model.fused_forward = False
+    with torch.no_grad():
+        served_first = model((torch.rand(1, 1, 16, 16, 64, device=hip_device) < 0.2))      # learns "served" for the bench bank
+        torch.cuda.synchronize()
+        model((torch.rand(1, 1, 16, 16, 64, device=hip_device) < 0.2))
+        assert model.__dict__["_prepared_verdict"]._state == 2
+        for layer in model.geneos.values():          # a bank far over the quantisation tolerance: sigma x 60
+            layer.geneo_params["sigma"].mul_(60.0)
+        odd = (torch.rand(1, 1, 16, 16, 40, device=hip_device) < 0.2)                      # Y % 16 != 0: not the walk's
+        model(odd)
+        torch.cuda.synchronize()
+        x = (torch.rand(2, 1, 64, 64, 64, device=hip_device) < 0.05)
+        got = model(x)
+        torch.cuda.synchronize()
+        assert model.__dict__["_prepared_verdict"]._state in (0, 1, 3)
+        again = model(x)
+        torch.cuda.synchronize()
+        assert model.__dict__["_prepared_verdict"]._state == 3
+        bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+        want = _hip.conv_bank(x, bank, lam, want_act=False, want_out=True)[1]
+        assert torch.equal(got, want) and torch.equal(again, want) and not bool(torch.isnan(got).any())
+    assert _hip.device_status()[0] == 0 and served_first is not None
+
+
+def test_a_write_through_data_is_seen_by_the_next_forward(hip_device):
+    """`p.data.fill_(..)`, `p.data = t` and an old-style `p.data.add_(..)` bump no `_version`; the model's
+    parameters count their `.data` accesses instead (scene_net._TrackedParameter), and every cache keys on that count."""
+    x = (torch.rand(2, 1, 32, 32, 64, device=hip_device) < 0.05)
+    for fused in (True, False):
+        model = _bench_model(hip_device)
+        model.fused_forward = fused
+        with torch.no_grad():
+            first = model(x)
+            torch.cuda.synchronize()
+            model(x)
+            p = model.geneos["cy_0"].geneo_params["radius"]
+            v0 = p._version
+            p.data.add_(0.5)                                         # invisible to _version ...
+            assert p._version == v0
+            moved = model(x)                                         # ... and still seen
+            fresh = _bench_model(hip_device)
+            fresh.fused_forward = fused
+            fresh.geneos["cy_0"].geneo_params["radius"].add_(0.5)
+            assert torch.equal(moved, fresh(x)) and not torch.equal(moved, first)
+            name = next(n for n in model.lambdas_dict if n != model.last_lambda)
+            model.lambdas_dict[name].data = model.lambdas_dict[name].data * 0.5      # the setter
+            fresh.lambdas_dict[name].mul_(0.5)
+            assert torch.equal(model(x), fresh(x))
+    assert _hip.device_status()[0] == 0
+
+
+def test_c3_share_32_tiles_of_128_cubed(hip_device, zwalk_variant):
+    """BASELINE C3's per-GPU share -- 32 tiles of 128^3, what `bench.py --grid 128 --batch 32` runs: voxelise -> prepared
+    contraction; the z-walk equals sn_conv_bank bit for bit over the whole batch, one tile meets the fp64 oracle directly,
+    no spin ever gave up (SCENE_Net.py:322-339)."""
+    if zwalk_variant != 2:
+        pytest.skip("the shipped variant only: 32 x 128^3 twice is 0.5 GB of outputs per variant")
+    from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile
+    specs, names, lambdas, last = synthetic_bank_spec()
+    model = sna.SceneNet({"cy": 6, "cone": 5, "neg": 5}, (9, 9, 9))
+    apply_bank_spec(model, specs, names, lambdas, last)
+    model = model.to(hip_device)
+    bank, lam = model.compute_bank(hip_device), model.effective_lambdas(hip_device)
+    tiles = [synthetic_tile(i, 120_000)[0] for i in range(32)]
+    occ = sna.voxelize_batch(sna.PointBatch.from_tiles(tiles, device=hip_device), (128,) * 3, occ_dtype=torch.bool).occ
+    assert tuple(occ.shape) == (32, 1, 128, 128, 128)
+    t0 = _hip.conv_i8_spin_timeouts()
+    c0 = _hip.conv_i8_path_counts()
+    (_, o_z), (_, o_r) = _both(occ, bank, lam, want_act=False)
+    assert _delta(c0, _hip.conv_i8_path_counts()) == (2, 0, 0)
+    assert torch.equal(o_z, o_r)
+    assert _hip.conv_i8_spin_timeouts() == t0 and _hip.device_status()[0] == 0
+    t = 17
+    ref = go.scenenet_forward(occ[t:t + 1].cpu().double(), specs, (9, 9, 9), lambdas, last, names=names)
+    assert (o_z[t:t + 1].cpu().double() - ref).abs().max().item() < TOL
+    assert float(ref.max()) > 0.05

@@ -290,6 +290,32 @@ def test_training_step_with_the_opener_riding_in_the_voxelisation(hip_device):
     for (nm, a), (_, b) in zip(model_e.named_parameters(), model_c.named_parameters()):
         assert torch.equal(a.detach(), b.detach()), nm
 
+    # a validation pass BETWEEN replays runs on the replayed weights.  The replayed optimiser graph writes the
+    # parameters through raw pointers -- no `_version` moves -- so replay() drops the model's parameter-derived caches
+    # (packed parameters, coefficients, K3L tables, learnt verdicts); without that the second pass below would reuse the
+    # first one's.  Reference: a freshly built model loaded with the same parameter values.
+    def fresh_copy():
+        m = sna.SceneNet({"cy": 2, "cone": 2, "neg": 1}, (9, 9, 9)).to(hip_device)
+        m.last_lambda = model_c.last_lambda
+        m.load_state_dict({k: v.detach().clone() for k, v in model_c.state_dict().items()})
+        return sna.ScenePipeline(m, (32, 32, 32), keep_labels=[15.0])
+
+    with torch.no_grad():
+        for fused in (True, False):
+            model_c.fused_forward = fused
+            seen = []
+            for _ in range(2):
+                val = pipe_c(batch_c)
+                torch.cuda.synchronize()
+                val = pipe_c(batch_c)                 # (second call: whatever the first one cached is now in use)
+                ref_pipe = fresh_copy()
+                ref_pipe.model.fused_forward = fused
+                assert torch.equal(val, ref_pipe(batch_c))
+                seen.append(val.clone())
+                for _ in range(2):
+                    cap.replay()
+            assert not torch.equal(seen[0], seen[1])      # the weights did move in between
+
 
 @pytest.mark.parametrize("crit_cls", [sna.GENEO_Tversky_Loss, sna.GENEO_Dice_Loss, sna.GENEO_Loss])
 @pytest.mark.parametrize("bf16", [False, True])
