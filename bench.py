@@ -62,9 +62,11 @@ def parse():
                          "eight at 64 and more.  [measured] a record costs ~2.5 us of GPU time plus host work next to "
                          "a queue that is barely ahead: 187.3 / 159.1 us per step with the records on every 4th / "
                          "every 50th of 200 steps")
-    ap.add_argument("--sustain-ms", type=float, default=400.0,
+    ap.add_argument("--sustain-ms", type=float, default=6000.0,
                     help="also time the same eager step back to back over at least this much wall time "
-                         "(`value_sustained`; 0 = skip)")
+                         "(`value_sustained`; 0 = skip).  6 s by default: an external sampler with a ~5 s period (the "
+                         "driver's gpu_busy probe, rocm-smi) then has at least one sample inside the loop; the loop also "
+                         "samples the device's own gpu_busy_percent (sysfs) every 100 ms and reports what it saw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 code path on a one-GPU box: every rank uses cuda:0, process group over gloo (not a "
@@ -146,6 +148,108 @@ def _late_imports():
     import scene_net_amd as sna
     from scene_net_amd.pipeline import job_sum, job_time_max
     from scene_net_amd.synthetic import apply_bank_spec, synthetic_bank_spec, synthetic_tile
+
+
+class BusySampler:
+    """gpu_busy_percent of this rank's device (amdgpu sysfs), sampled every 100 ms on a thread while the sustained loop runs:
+    corroboration from OUTSIDE the HIP event / host clock pair every other number here rests on."""
+
+    def __init__(self, index):
+        import glob
+        import threading
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+        self.index, self.samples, self._stop = index, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.wait(0.1):
+            vals = []
+            for p in self.paths:
+                try:
+                    vals.append(int(open(p).read().strip()))
+                except (OSError, ValueError):
+                    pass
+            if vals:
+                self.samples.append(max(vals))   # (one GPU per box here; the busiest card otherwise)
+
+    def start(self):
+        if self.paths:
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self.paths and self._thread.is_alive():
+            self._thread.join(timeout=1.0)
+        if not self.samples:
+            return {"samples": 0, "note": "no readable gpu_busy_percent in sysfs"}
+        s_ = self.samples
+        return {"samples": len(s_), "mean": sum(s_) / len(s_), "min": min(s_), "max": max(s_),
+                "frac_samples_busy_ge_90": sum(1 for v in s_ if v >= 90) / len(s_)}
+
+
+REFERENCE_CHECKPOINT = {   # experiments/scenenet_ts40k/.../checkpoints/FBetaScore.ckpt, the 13 trained scalars (SURVEY 8c)
+    "cy_0": dict(radius=0.998896, sigma=1.199054),
+    "cone_0": dict(apex=0.0, cone_inc=0.565547, cone_radius=4.000988, radius=1.5, sigma=0.955910),
+    "neg_0": dict(neg_factor=0.127053, radius=3.000918, sigma=0.605097),
+    "lambdas": {"cy_0": 0.024178, "cone_0": 0.608911, "neg_0": 0.366911},
+}
+
+
+def reference_defaults_extra(sna, dev, ev, spin, args, B=64):
+    """ms per call and roofline fractions of the module as the reference configures it: SceneNet({'cy':1,'cone':1,'neg':1},
+    (9,5,5)) with the checkpoint's scalars on 64 resident tiles of 64^3 -- `model(x)` (the head: what LitSceneNet.forward
+    returns) and `model(x, return_bank_activations=True)`; plus the whole step from points."""
+    import torch
+    geneo_num, ks = {"cy": 1, "cone": 1, "neg": 1}, (9, 5, 5)
+    model = sna.SceneNet(geneo_num, ks)
+    with torch.no_grad():
+        for name in ("cy_0", "cone_0", "neg_0"):
+            for k, v in REFERENCE_CHECKPOINT[name].items():
+                model.geneos[name].geneo_params[k].fill_(v)
+            model.lambdas_dict[f"lambda_{name}"].fill_(REFERENCE_CHECKPOINT["lambdas"][name])
+    model.last_lambda = "lambda_cy_0"
+    model = model.to(dev)
+    tiles, labels = zip(*[synthetic_tile(50_000 + i, args.points) for i in range(B)])
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=dev)
+    pipe = sna.ScenePipeline(model, (64,) * 3)
+    del tiles, labels
+    V, G, ntaps = 64 ** 3, 3, 9 * 5 * 5
+    flops = 2.0 * V * ntaps * G * B
+    out = {"config": f"{B} tiles x {args.points} points, 64^3 grid, kernel (9,5,5), 3 GENEOs (cy 1, cone 1, neg 1), the "
+                     "checkpoint's 13 scalars; defaults_config.yml:16-19,33-40", "flops_per_call_dense": flops}
+    with torch.no_grad():
+        occ = pipe.voxelize(batch).occ
+        calls = {"head_only": lambda: model(occ), "with_activations": lambda: model(occ, return_bank_activations=True),
+                 "whole_step_from_points": lambda: pipe(batch)}
+        for name, fn in calls.items():
+            for _ in range(3):
+                fn()
+            spin(fn, args.spinup_ms / 4)
+            n = 30
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            # compulsory bytes: occupancy in (1 B / voxel), head out (4 B), activations out (4 B x G)
+            bytes_ = B * V * (1 + 4 + (4 * G if name == "with_activations" else 0))
+            if name == "whole_step_from_points":
+                bytes_ += B * args.points * 24
+            out[name] = {"ms_per_call": ms, "tiles_per_s": B / (ms * 1e-3),
+                         "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
+                         "frac_of_int8_peak_dense": flops / (ms * 1e-3) / 1e12 / PEAK_I8_MFMA_TOPS,
+                         "compulsory_GBps": bytes_ / (ms * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": bytes_ / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        fused = bool(model.fused_forward and sna._hip.conv_fused_supported(occ, ks))
+        out["head_only"]["kernel"] = ("conv_lin_i8_kernel (K3L: one combined kernel sum_i lambda_i K_i, int8 Toeplitz GEMM)"
+                                      if fused else "sn_conv_bank")
+        out["with_activations"]["kernel"] = ("conv_occ_i8_kernel (four-copy int8 kernel: the only int8 form for ky != 9; "
+                                             "3 of its 16 kernel rows carry a kernel)")
+        out["bound"] = ("hbm: 270 flop per compulsory byte (head only) is under the int8 matrix pipe's balance of 625 -- "
+                        "the dense-convention fraction of the int8 peak cannot pass ~0.43 on this configuration")
+    return out
 
 
 def main():
@@ -455,6 +559,14 @@ def main():
         msg = f"{type(exc).__name__}: {exc}"[:200]
         graph_info = {"skipped": msg} if "skipped" in msg else {"error": msg}
 
+    # ---- what the REFERENCE'S OWN DEFAULTS run (experiments/scenenet_ts40k/defaults_config.yml:16-19,33-40 and the committed
+    # checkpoint): kernel (9, 5, 5), one GENEO per family, the checkpoint's 13 trained scalars, 64 tiles of 64^3.
+    # A user who drops this package into core/lit_modules unchanged gets THIS, not C2's 16 x 9^3 bank.  2 V 225 x 3 = 354
+    # MFLOP per tile against 0.26 MB in + 1.05 MB out: 270 flop/B, under the int8 pipe's balance (625) -- the bound is HBM.
+    ref_defaults = None
+    if not args.no_extras and args.grid == 64:
+        ref_defaults = reference_defaults_extra(sna, dev, ev, spin, args)
+
     # which BASELINE config this run is (derived from the arguments, never assumed)
     if (B, args.points, args.grid) == (32, 100_000, 64):
         wl_tag = "C2"
@@ -469,9 +581,12 @@ def main():
     sustained = None
     if args.sustain_ms > 0:
         n_s = max(args.steps, int(args.sustain_ms / max(dt / args.steps * 1e3, 1e-3)) + 1)
+        busy = BusySampler(local_rank)
+        busy.start()
         dt_s, _ = timed_job(lambda: step(False), n_s)
+        busy_info = busy.stop()
         sustained = {"value": B * n_s * n_gpus / dt_s, "ms_per_step": dt_s / n_s * 1e3, "steps": n_s,
-                     "wall_s": dt_s}
+                     "wall_s": dt_s, "gpu_busy_percent": busy_info}
 
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes/launch from separate rocprofv3 --pmc passes
@@ -526,6 +641,7 @@ def main():
                            "unit": "GB/s", "frac": vox_gbs / PEAK_HBM_GBS, "traffic": traffic.get("voxel_stage"),
                            "stage_ms": vox_ms, "stages_timed": len(vox_ev), "bytes_per_stage": vox_bytes},
         "fused_linear": fused_info,
+        "reference_defaults": ref_defaults,
         "graph_replay": graph_info,
         "skip_empty_tiles": skip_info,
     }

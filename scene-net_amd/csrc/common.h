@@ -30,6 +30,7 @@ inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_
 
 int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 int option_conv_i8_fold();            // cabi.hip (sn_set_option "conv_i8_fold", default 1): 0 = never try the folded int8 kernel (conv_i8s.hip)
+int option_voxel_onepass();           // cabi.hip (sn_set_option "voxel_onepass", default 1): 0 = the two-kernel form (bbox, then binning) on every grid
 int option_conv_i8z_inject_fault();   // cabi.hip (sn_set_option "conv_i8z_inject_fault"): test hook, see conv_i8z.inc's prologue
 int option_conv_i8z_variant();        // cabi.hip (sn_set_option "conv_i8z_variant"): shape of the z-walk kernel's rounds (conv_i8z.inc)
 int option_corr_sparse_tile_bytes();  // cabi.hip (sn_set_option "corr_sparse_tile_bytes"): input bytes per job of the sparse correlation (0: 2048, the maximum)
@@ -101,6 +102,8 @@ __device__ __forceinline__ void sticky_latch(int32_t* sticky, int code, int a, i
     // (a, b are wave-uniform; made opaque HERE so that hipcc does not materialise them in vector registers ahead of the hot
     // loop the latch sits behind -- [measured in the ISA] it hoisted a v_mov of blockIdx.x out of the z-walk's ticket loop and
     // spilled it: the kernel's only scratch use)
+    a = __builtin_amdgcn_readfirstlane(a);   // (uniform by contract; the readfirstlane makes it so for the register allocator,
+    b = __builtin_amdgcn_readfirstlane(b);   // whatever it thinks of the caller's expression)
     asm volatile("" : "+s"(a), "+s"(b));
     if (__hip_atomic_exchange(&sticky[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
         __hip_atomic_store(&sticky[2], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

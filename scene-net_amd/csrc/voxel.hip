@@ -23,6 +23,7 @@
 //     flag, and flagged tiles are redone by the (gated) counting kernels.
 #include "common.h"
 
+#include <atomic>
 #include <type_traits>
 #include <cfloat>
 #include <climits>
@@ -670,6 +671,236 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
     }
 }
 
+// ---------------------------------------------------------------- one pass over the points (round 4)
+// bbox_partial_kernel + occ_partial_kernel read every point twice -- the box pass from HBM, the binning pass from the
+// Infinity Cache -- and the binning pass is latency bound (six dependent trips of two points per thread).  Here a thread
+// keeps its share of the tile in REGISTERS: kOnePairs pairs of points (48 B each, three 16-byte loads, all requested before
+// the first one is used), takes their min / max, the tile's 16 workgroups exchange partial boxes through memory, every
+// workgroup derives the descriptor (the same code, the same bits, as before) and bins its points out of the registers into
+// its LDS bitmap.  One launch instead of two, 77 MB of point traffic instead of 154.
+//
+// The exchange: workgroup `part` of tile b publishes {box[6], tag} in partial_ws[b][part][0..7] -- the seven words with
+// agent-scope atomic stores (the 16 workgroups of a tile sit on all eight XCDs, each behind its own L2), the tag last,
+// behind a release -- and waits until all kOccParts tags of its tile carry this launch's tag, then reads the boxes with
+// agent-scope loads.  The tag is (magic | epoch), the epoch a process-wide launch counter: whatever the scratch block held
+// before cannot pass for it; occ_finalize_kernel, which runs behind this launch, zeroes the tags, so a captured graph (same
+// epoch at every replay) starts clean each time.
+// Forward progress: a workgroup publishes before it waits, and waits only for workgroups of ITS tile.  Each XCD is handed
+// its share of the grid in order (tile-major: blockIdx.y = tile), so the lowest unfinished tile always has every workgroup
+// dispatched or about to be; at C2 (16 x 32 workgroups, two per CU) the whole grid is resident at once.
+// Tiles with more than kOnePairs x 2 x 512 x 16 = 114 688 points: the surplus pairs are streamed from memory in both
+// phases, as the two-kernel form does.
+constexpr int kOnePairs = 7;
+#ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/vox_timing.py
+__device__ unsigned long long g_vox_t[1024 * 8];   // per workgroup: 0 start, 1 points in + min/max, 2 published, 3 all tags seen, 4 descriptor, 5 binned, 6 end
+#define SN_VT(k) do { if (threadIdx.x == 0) g_vox_t[(blockIdx.y * gridDim.x + blockIdx.x) % 1024 * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define SN_VT(k) do {} while (0)
+#endif
+constexpr unsigned long long kOneMagic = 0x5ce7e000ull << 32;
+
+template <bool kAligned>
+__global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* __restrict__ pts,
+                                                                  const double* __restrict__ labels,
+                                                                  const int64_t* __restrict__ offsets, int nx, int ny,
+                                                                  int nz, int words, int planes, KeepLabels keep,
+                                                                  uint32_t* __restrict__ bits_ws,
+                                                                  int32_t* __restrict__ dropped_parts,
+                                                                  int32_t* __restrict__ flags,
+                                                                  double* __restrict__ box_parts, unsigned epoch,
+                                                                  int regular, double* __restrict__ desc_out,
+                                                                  double* __restrict__ bbox_out, int32_t* sticky,
+                                                                  int rider_rows, BankRider r) {
+    if ((int)blockIdx.y < rider_rows) {
+        // K2 as riders (the first grid rows: dispatched first), 256 of the 512 threads build kernel g + its preparation
+        __shared__ float bank_lds[729 + 9 + 1 + 8 + 1];
+        const int g = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        if (g < r.nblocks && threadIdx.x < kBankThreads)
+            geneo_bank_body<true>(bank_lds, g, threadIdx.x, r.params, r.kinds, 9, 9, 9, r.bank, r.status, r.G, r.lambdas,
+                                  r.order, r.last, r.lambdas_out, r.prep);
+        return;
+    }
+    __shared__ int dropped_blk;
+    __shared__ double lohi[6];
+    __shared__ double red[kOccThreads / 64][6];
+    __shared__ double box16[kOccParts][6];
+    extern __shared__ double smem[];
+    const int ne = nx + ny + nz + 3;
+    double* edges = smem;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(smem + ((ne + 1) & ~1));
+    const int b = (int)blockIdx.y - rider_rows, part = blockIdx.x, tid = threadIdx.x;
+    const bool want_tower = (planes == 2);
+    if (tid == 0) dropped_blk = 0;
+    SN_VT(0);
+
+    // ---- phase 1: this thread's points into registers, their min / max
+    const long p0 = offsets[b], p1 = offsets[b + 1];
+    long q0 = kAligned ? p0 + (p0 & 1) : p0;
+    if (q0 > p1) q0 = p1;
+    const long npair = (p1 - q0) >> 1;
+    const long gtid = (long)part * kOccThreads + tid, gstride = (long)kOccParts * kOccThreads;
+    const double2* src = reinterpret_cast<const double2*>(pts + 3 * q0);
+    double2 a[kOnePairs][3];
+    unsigned kept = 0u;      // bit 2k / 2k + 1: the pair's first / second point carries a kept label (GT plane)
+#pragma unroll
+    for (int k = 0; k < kOnePairs; ++k) {
+        const long j = gtid + k * gstride;
+        if (j < npair) {
+            if constexpr (kAligned) {
+                a[k][0] = src[3 * j]; a[k][1] = src[3 * j + 1]; a[k][2] = src[3 * j + 2];
+            } else {
+                const double* q = pts + 3 * (q0 + 2 * j);
+                a[k][0] = make_double2(q[0], q[1]); a[k][1] = make_double2(q[2], q[3]); a[k][2] = make_double2(q[4], q[5]);
+            }
+        }
+    }
+    if (want_tower) {
+#pragma unroll
+        for (int k = 0; k < kOnePairs; ++k) {
+            const long j = gtid + k * gstride;
+            if (j < npair) {
+                const double l0 = labels[q0 + 2 * j], l1 = labels[q0 + 2 * j + 1];
+                kept |= (is_kept(l0, keep) ? 1u : 0u) << (2 * k) | (is_kept(l1, keep) ? 2u : 0u) << (2 * k);
+            }
+        }
+    }
+    // (the bitmap is cleared while the loads are in flight)
+    for (int i = tid; i < words * planes; i += kOccThreads) bits[i] = 0u;
+    // the points that are nobody's pair: an odd first one (aligned form), an odd last one -- thread 0 of part 0
+    const bool lone_first = kAligned && (p0 & 1) && p0 < p1, lone_last = ((p1 - q0) & 1) != 0;
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    auto take = [&](double x, double y, double z) {
+        mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x);
+        mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
+        mn[2] = fmin(mn[2], z); mx[2] = fmax(mx[2], z);
+    };
+#pragma unroll
+    for (int k = 0; k < kOnePairs; ++k) {
+        if (gtid + k * gstride < npair) {
+            take(a[k][0].x, a[k][0].y, a[k][1].x);
+            take(a[k][1].y, a[k][2].x, a[k][2].y);
+        }
+    }
+    for (long j = gtid + (long)kOnePairs * gstride; j < npair; j += gstride) {   // (tiles beyond the register budget)
+        const double* q = pts + 3 * (q0 + 2 * j);
+        take(q[0], q[1], q[2]);
+        take(q[3], q[4], q[5]);
+    }
+    if (gtid == 0) {
+        if (lone_first) take(pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2]);
+        if (lone_last) take(pts[3 * (p1 - 1)], pts[3 * (p1 - 1) + 1], pts[3 * (p1 - 1) + 2]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fmin(mn[c], __shfl_xor(mn[c], o, 64));
+            mx[c] = fmax(mx[c], __shfl_xor(mx[c], o, 64));
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            red[tid >> 6][c] = mn[c];
+            red[tid >> 6][3 + c] = mx[c];
+        }
+    }
+    __syncthreads();
+    SN_VT(1);
+    // ---- the exchange
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(box_parts) + (size_t)b * kOccParts * 8;
+    const unsigned long long tag = kOneMagic | epoch;
+    if (tid < 6) {
+        double v = red[0][tid];
+        for (int w = 1; w < kOccThreads / 64; ++w) v = (tid < 3) ? fmin(v, red[w][tid]) : fmax(v, red[w][tid]);
+        __hip_atomic_store(&slots[part * 8 + tid], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The tag goes out behind the six values WITHOUT a release fence: all seven words are agent-scope atomic stores (write
+    // through: nothing else this workgroup has written needs to be visible to anybody), the six values leave in ONE wave
+    // instruction of wave 0, and s_waitcnt vmcnt(0) in that wave waits for their acknowledgement before lane 0 issues the tag.
+    // [measured] with `release` on the tag and an agent-scope `acquire` fence behind the wait -- an L2 write-back and an L2
+    // invalidate per workgroup, 512 of each -- the kernel took 58.9 us against 36 us for the two kernels it replaces.
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store(&slots[part * 8 + 6], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    SN_VT(2);
+    if (tid < kOccParts) {
+        int spins = 0;
+        while (__hip_atomic_load(&slots[tid * 8 + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+            if (++spins > (1 << 22)) {   // cannot happen (see "forward progress" above); never hang the GPU -- and never be
+                sn::sticky_latch(sticky, 4, b, part);   // quiet about it: the tile's box, hence its grid, would be wrong
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    SN_VT(3);
+    // (the boxes are read with agent-scope atomic loads, issued behind the tags' loads: no stale line of an earlier launch's
+    // exchange can be taken for them, and no cache needs invalidating)
+    if (tid < kOccParts * 6)
+        box16[tid / 6][tid % 6] = __longlong_as_double((long long)__hip_atomic_load(
+            &slots[(tid / 6) * 8 + tid % 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    // the descriptor from the 16 partial boxes: derive_desc's own code on the LDS copy (same bits in every workgroup)
+    derive_desc(&box16[0][0], kOccParts, 0, nx, ny, nz, regular, lohi, edges, kOccThreads);
+    if (part == 0) {
+        double* dd = desc_out + (size_t)b * SN_DESC_LEN(nx, ny, nz);
+        for (int i = tid; i < 6 + ne; i += kOccThreads) dd[i] = (i < 6) ? lohi[i] : edges[i - 6];
+        if (bbox_out && tid < 6) {
+            double v = (tid < 3) ? DBL_MAX : -DBL_MAX;
+            for (int pp = 0; pp < kOccParts; ++pp) v = (tid < 3) ? fmin(v, box16[pp][tid]) : fmax(v, box16[pp][tid]);
+            bbox_out[b * 6 + tid] = v;
+        }
+    }
+    SN_VT(4);
+    // ---- phase 2: bin out of the registers
+    Binner bin;
+    bin.init(edges, lohi, nx, ny, nz);
+    int dropped = 0;
+    auto put = [&](double x, double y, double z, bool tower) {
+        const int f = bin.flat(x, y, z);
+        if (f < 0) { ++dropped; return; }
+        atomicOr(&bits[f >> 5], 1u << (f & 31));
+        if (tower) atomicOr(&bits[words + (f >> 5)], 1u << (f & 31));
+    };
+#pragma unroll
+    for (int k = 0; k < kOnePairs; ++k) {
+        if (gtid + k * gstride < npair) {
+            put(a[k][0].x, a[k][0].y, a[k][1].x, want_tower && ((kept >> (2 * k)) & 1u));
+            put(a[k][1].y, a[k][2].x, a[k][2].y, want_tower && ((kept >> (2 * k + 1)) & 1u));
+        }
+    }
+    for (long j = gtid + (long)kOnePairs * gstride; j < npair; j += gstride) {
+        const double* q = pts + 3 * (q0 + 2 * j);
+        put(q[0], q[1], q[2], want_tower && is_kept(labels[q0 + 2 * j], keep));
+        put(q[3], q[4], q[5], want_tower && is_kept(labels[q0 + 2 * j + 1], keep));
+    }
+    if (gtid == 0) {
+        if (lone_first) put(pts[3 * p0], pts[3 * p0 + 1], pts[3 * p0 + 2], want_tower && is_kept(labels[p0], keep));
+        if (lone_last) {
+            const long k = p1 - 1;
+            put(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], want_tower && is_kept(labels[k], keep));
+        }
+    }
+    __syncthreads();
+    SN_VT(5);
+    uint32_t* out = bits_ws + ((size_t)b * kOccParts + part) * (size_t)planes * words;
+    for (int i = tid; i < words; i += kOccThreads) {
+        out[i] = bits[i];
+        if (want_tower) out[words + i] = bits[words + i];
+    }
+    if (dropped) atomicAdd(&dropped_blk, dropped);  // LDS
+    __syncthreads();
+    if (tid == 0) {
+        dropped_parts[b * kOccParts + part] = dropped_blk;
+        if (flags && part == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
+    }
+    SN_VT(6);
+}
+
 // OR of the `parts` partial bitmaps of one tile (plane 0 = occupancy, 1 = towers), word w
 __device__ __forceinline__ uint32_t merged_word(const uint32_t* __restrict__ src, int parts, int planes, int words,
                                                 int plane, long w) {
@@ -710,8 +941,13 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
                                                                 int32_t* __restrict__ flags,
                                                                 const int32_t* __restrict__ dropped_parts,
                                                                 int32_t* __restrict__ dropped,
-                                                                const int32_t* __restrict__ dims, int nx) {
+                                                                const int32_t* __restrict__ dims, int nx,
+                                                                unsigned long long* __restrict__ exchange_slots) {
     const int b = blockIdx.y;
+    // (the one-pass kernel's exchange tags of this tile: zeroed here, behind that launch, so that a replayed graph --
+    // whose launches carry the same tag every time -- never finds the previous replay's)
+    if (exchange_slots && blockIdx.x == 0 && threadIdx.x < kOccParts)
+        exchange_slots[((size_t)b * kOccParts + threadIdx.x) * 8 + 6] = 0ull;
     if (dropped && blockIdx.x == 0 && threadIdx.x == 0) {
         int t = 0;
         for (int p = 0; p < parts; ++p) t += dropped_parts[b * parts + p];
@@ -1121,13 +1357,20 @@ extern "C" int sn_voxel_finalize(const int32_t* counts, const int32_t* tower_cou
     return sn::check_launch("sn_voxel_finalize");
 }
 
+// the one-pass kernel serves grids whose bitmap(s) fit one workgroup's LDS (no z-slabs): 64^3 with or without the GT plane
+static bool onepass_eligible(int nx, int ny, int nz, int planes) {
+    const size_t V = (size_t)nx * ny * nz;
+    return sn::option_voxel_onepass() && V % 32 == 0 && (V / 32) * planes <= (size_t)kMaxOccWords;
+}
+
 // sn_voxel_occupancy (descriptor given) and sn_voxel_occupancy_fused (box_parts given: the binning kernel derives the
 // descriptor itself and writes it to `desc`)
 static int occupancy_impl(const double* pts, const double* labels, const int64_t* offsets, int B, double* desc, int nx,
                           int ny, int nz, const double* keep_labels_host, int n_keep, uint32_t* bits_ws, void* occ,
                           void* gt_occ, int out_dtype, int32_t* flags, int32_t* dropped, int32_t* counts_ws,
                           int32_t* towers_ws, const double* box_parts, int nbparts, int regular, double* bbox_out,
-                          sn_stream_t stream, const int32_t* dims = nullptr) {
+                          sn_stream_t stream, const int32_t* dims = nullptr, const BankRider* onepass_rider = nullptr,
+                          bool onepass = false) {
     if (!pts || !offsets || !desc || !bits_ws || !occ)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: null pointer");
     if (B <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -1166,7 +1409,24 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
     const size_t lds1 =
         (size_t)((ne + 1) & ~1) * sizeof(double) + (size_t)(words / slabs) * planes * sizeof(uint32_t);
     const bool al = aligned16(pts) && (!labels || aligned16(labels));
-    {
+    unsigned long long* exchange = nullptr;
+    if (onepass) {
+        // ONE pass over the points: the box, the descriptor and the bitmap in one launch (occ_onepass_kernel); `box_parts` is
+        // the exchange area.  Riders (K2) in the first grid rows when a bank was handed in.
+        static std::atomic<unsigned> epoch_ctr{0};
+        const unsigned epoch = epoch_ctr.fetch_add(1, std::memory_order_relaxed) + 1;
+        BankRider none{};
+        const BankRider& r = onepass_rider ? *onepass_rider : none;
+        const int rider_rows = onepass_rider ? (r.nblocks + kOccParts - 1) / kOccParts : 0;
+        exchange = reinterpret_cast<unsigned long long*>(const_cast<double*>(box_parts));
+        const bool al_p = aligned16(pts);
+        auto kern = al_p ? occ_onepass_kernel<true> : occ_onepass_kernel<false>;
+        if (sn::ensure_dynamic_lds((const void*)kern, 96 * 1024) != hipSuccess)
+            return sn::check_launch("sn_voxel_occupancy_fused(hipFuncSetAttribute)");
+        hipLaunchKernelGGL(kern, dim3(kOccParts, B + rider_rows), dim3(kOccThreads), lds1, s, pts, labels, offsets, nx, ny, nz,
+                           words, planes, keep, bits_ws, dropped_parts, flags, const_cast<double*>(box_parts), epoch, regular,
+                           desc, bbox_out, sn::sticky_device_ptr(), rider_rows, r);
+    } else {
         auto kern = al ? occ_partial_kernel<true> : occ_partial_kernel<false>;
         if (sn::ensure_dynamic_lds((const void*)kern, 96 * 1024) != hipSuccess)
             return sn::check_launch("sn_voxel_occupancy(hipFuncSetAttribute)");
@@ -1179,10 +1439,11 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
     if (C > blocks_per_tile(B, 2048)) C = blocks_per_tile(B, 2048);
     if (out_dtype == SN_U8)
         hipLaunchKernelGGL(occ_finalize_kernel<uint8_t>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes,
-                           parts, rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped, dims, nx);
+                           parts, rows, ny, V, (uint8_t*)occ, (uint8_t*)gt_occ, flags, dropped_parts, dropped, dims, nx,
+                           exchange);
     else
         hipLaunchKernelGGL(occ_finalize_kernel<float>, dim3(C, B), dim3(kThreads), 0, s, bits_ws, words, planes, parts,
-                           rows, ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped, dims, nx);
+                           rows, ny, V, (float*)occ, (float*)gt_occ, flags, dropped_parts, dropped, dims, nx, exchange);
     // flagged tiles (a y column might be full): redone exactly by one gated launch
     if (flags && counts_ws) {
         const size_t lds3 = (size_t)ne * sizeof(double) + (size_t)ny * sizeof(int);
@@ -1218,15 +1479,18 @@ extern "C" int sn_voxel_occupancy_fused(const double* pts, const double* labels,
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy_fused: non-positive extent (B=%d n=%d,%d,%d)", B, nx,
                         ny, nz);
     hipStream_t s = sn::as_stream(stream);
-    dim3 grid(SN_BBOX_PARTS, B);
-    if (aligned16(pts))
-        hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
-    else
-        hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
-    if (int rc = sn::check_launch("sn_voxel_occupancy_fused(bbox)")) return rc;
+    const bool one = onepass_eligible(nx, ny, nz, gt_occ ? 2 : 1);
+    if (!one) {
+        dim3 grid(SN_BBOX_PARTS, B);
+        if (aligned16(pts))
+            hipLaunchKernelGGL(bbox_partial_kernel<true>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+        else
+            hipLaunchKernelGGL(bbox_partial_kernel<false>, grid, dim3(kThreads), 0, s, pts, offsets, partial_ws);
+        if (int rc = sn::check_launch("sn_voxel_occupancy_fused(bbox)")) return rc;
+    }
     return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
                           out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
-                          bbox, stream);
+                          bbox, stream, nullptr, nullptr, one);
 }
 
 // the bounding-box launch of the fused entry points, with K2's workgroups as riders when a bank is handed in
@@ -1272,6 +1536,13 @@ extern "C" int sn_voxel_occupancy_fused_bank(const double* pts, const double* la
     if (int rc = check_rider("sn_voxel_occupancy_fused_bank", params, kinds, G, kz, kx, ky, bank, lambdas, order, last,
                              lambdas_out, prep))
         return rc;
+    if (onepass_eligible(nx, ny, nz, gt_occ ? 2 : 1)) {   // K2 rides in the one-pass kernel's first grid rows
+        const BankRider r{params, kinds, bank, status, static_cast<uint8_t*>(prep), lambdas, order, lambdas_out, last, G,
+                          16 * ((G + 15) / 16) + (lambdas ? 1 : 0)};
+        return occupancy_impl(pts, labels, offsets, B, desc, nx, ny, nz, keep_labels_host, n_keep, bits_ws, occ, gt_occ,
+                              out_dtype, flags, dropped, counts_ws, towers_ws, partial_ws, SN_BBOX_PARTS, regular ? 1 : 0,
+                              bbox, stream, nullptr, &r, true);
+    }
     launch_bbox_with_riders(pts, offsets, partial_ws, B, params, kinds, G, bank, status, lambdas, order, last, lambdas_out,
                             prep, sn::as_stream(stream));
     if (int rc = sn::check_launch("sn_voxel_occupancy_fused_bank(bbox + bank)")) return rc;
@@ -1393,3 +1664,10 @@ extern "C" int sn_grid_to_points(const void* grid, int dtype, int n0, int n1, in
 #undef SN_G2P
     return sn::check_launch("sn_grid_to_points");
 }
+
+#ifdef SN_CONV_TIMING
+extern "C" void sn_debug_vox_times(unsigned long long* host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_vox_t), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
