@@ -58,7 +58,7 @@ def run(name, fn):
 
 
 run("headline step (K1 + riders, K3'z)", headline)
-assert _hip.conv_i8_spin_timeouts() == 0
+assert _hip.conv_i8_spin_timeouts() == 0 and _hip.device_status()[0] == 0
 run("contraction (K3')", contraction)
 run("linear (K3L)", linear)
 _hip.set_option("conv_skip_empty_tiles", 1)
