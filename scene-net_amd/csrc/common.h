@@ -76,6 +76,13 @@ enum ExtraOption {
     kOptCount
 };
 int option_extra(ExtraOption which);   // cabi.hip
+// The kernels' side of those switches: SN_DBG(shape, bit) is a COMPILE-TIME false in the product build -- no kernel carries
+// a runtime test of a debug word; in a -DSN_CONV_DEBUG build it reads the shape's dbg field.
+#ifdef SN_CONV_DEBUG
+#define SN_DBG(shape, bit) (((shape).dbg & (bit)) != 0)
+#else
+#define SN_DBG(shape, bit) false
+#endif
 // Wrong-result timing switches (a skipped epilogue, idle waves ...) exist only in builds made with -DSN_CONV_DEBUG
 // (make EXTRA=-DSN_CONV_DEBUG): in the product they read as 0 whatever the environment says.
 inline int debug_env_int(const char* name) {

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
     // Tile order: static (w, w+grid, ...) or, with a ticket counter (conv_skip_empty_tiles: tiles then cost very
     // different amounts), dynamic -- one thread draws the ticket of the tile after next while the rounds run.
     int tile = blockIdx.x;
-    if (tile >= s.ntiles || (s.dbg & 8)) return;
+    if (tile >= s.ntiles || SN_DBG(s, 8)) return;
     if (ticket && tid == 0) *tnext = gridDim.x + ticket_draw(ticket);
     if (dma_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
     __syncthreads();  // the staged bank (aliasing the halo area) is dead from here on
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         if (lane == 0) wseen[wave] = w;
     }
     __syncthreads();
-    if (s.dbg & 16) return;
+    if (SN_DBG(s, 16)) return;
     SN_T(4);
 
     while (tile < s.ntiles) {
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
 #endif
         const TileCoord c = tile_coord(s, tile);
         const int next = ticket ? *tnext : tile + (int)gridDim.x;
-        const bool has_next = (next < s.ntiles) && !(s.dbg & 2);
+        const bool has_next = (next < s.ntiles) && !SN_DBG(s, 2);
         if (kStage && has_next) halo_dma_issue<YPB>(stage, x, s, tile_coord(s, next), wave, lane, XP, rows);
         int after_next = 0;
         if (ticket && tid == 0) after_next = gridDim.x + ticket_draw(ticket);
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             // ---- epilogue: recombine the digits, then the same head as the fp32 kernel
             const int gz = c.z0 + lz;
             if (gz >= s.Z) continue;
-            if (s.dbg & 1) {  // timing experiment: keep the accumulators live, skip the epilogue
+            if (SN_DBG(s, 1)) {  // timing experiment: keep the accumulators live, skip the epilogue
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
         if (lane == 0) g_conv_w[blockIdx.x * 8 + wave] += wall_clock64() - t_tile;
 #endif
         if (kStage) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-        if (!(s.dbg & 4)) __syncthreads();  // every wave is done reading the halo tile (and every DMA landed)
+        if (!SN_DBG(s, 4)) __syncthreads();  // every wave is done reading the halo tile (and every DMA landed)
         SN_TACC(6, t_tile);
 #ifdef SN_CONV_TIMING
         const unsigned long long t_sw = wall_clock64();
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void conv_occ_i8_kernel(const uint8_t* __
             if (lane == 0) wseen[wave] = w;
         }
         if (ticket && tid == 0) *tnext = after_next;  // everybody read the old value before the barrier above
-        if (!(s.dbg & 4)) __syncthreads();
+        if (!SN_DBG(s, 4)) __syncthreads();
         SN_TACC(7, t_sw);
         tile = next;
     }

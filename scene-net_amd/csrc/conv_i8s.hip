@@ -348,7 +348,7 @@ __device__ __forceinline__ void finish_round(const SH& s, const TileCoord& c, in
                                              const float* lamhi, OT* __restrict__ act, OT* __restrict__ out, size_t V) {
     const int gz = c.z0 + lz;
     if (gz >= s.Z) return;
-    if (s.dbg & 1) {
+    if (SN_DBG(s, 1)) {
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -599,7 +599,7 @@ __device__ __forceinline__ bool conv_occ_i8s_body(const uint8_t* __restrict__ x,
         lamsc[tid] = ls;
         lamhi[tid] = 65536.0f * ls;   // exact
     }
-    if (my_tiles == 0 || (s.dbg & 8)) {
+    if (my_tiles == 0 || SN_DBG(s, 8)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return false;
     }
@@ -624,7 +624,7 @@ __device__ __forceinline__ bool conv_occ_i8s_body(const uint8_t* __restrict__ x,
         const unsigned long long t_tile = SN_WNOW();
         if (it >= 2) healthy &= wave_wait(&landed[bi], kWaves * (it / kNB + 1 - (bi < 2 ? 1 : 0)));
         SN_WT(0, t_tile);
-        const bool dma_next = it + 2 < my_tiles && !(s.dbg & 2);
+        const bool dma_next = it + 2 < my_tiles && !SN_DBG(s, 2);
         // this wave's pieces of halo it+2.  Its ring slot was last read by tile it-1: every wave must be past that
         // tile -- two rounds into tile `it` they are ([measured] one round in, waves 0-3 waited ~4 us per tile for the
         // younger wave of their SIMD); a wave with fewer rounds issues after them
@@ -655,7 +655,7 @@ __device__ __forceinline__ bool conv_occ_i8s_body(const uint8_t* __restrict__ x,
             if (k == k_dma && dma_pending) dma_ahead();
             SN_WT(4, t_r0);
             const unsigned long long t_r1 = SN_WNOW();
-            if ((s.dbg & 128) && wave >= kWaves / 2) continue;   // timing experiment: one wave per SIMD works
+            if (SN_DBG(s, 128) && wave >= kWaves / 2) continue;   // timing experiment: one wave per SIMD works
             const int lz = round >> hx_shift, lx = (round & (half_tx - 1)) * 2;   // TX / 2 is a power of two (cand[] below)
             const uint8_t* xb = hb + ((lz * s.XP + lx) * DW + n + D0) * 4;
 

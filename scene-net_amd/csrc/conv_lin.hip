@@ -177,12 +177,12 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     }
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
     const float scale = misc[0];
-    if (s.dbg & 1) return;
+    if (SN_DBG(s, 1)) return;
 
     // Deferred epilogue: a tile's 16 outputs per lane stay in registers as pre-activations and are finished
     // (exp / rcp / 16-byte stores) BETWEEN the MFMAs of the next tile's first 16 steps, instead of in a phase where
     // the matrix pipe idles.  Needs >= 16 steps; smaller kernels finish each tile at once.
-    const bool defer = s.nsteps >= 16 && !(s.dbg & 16);
+    const bool defer = s.nsteps >= 16 && !SN_DBG(s, 16);
     float pv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) pv[k] = 0.f;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         const uint8_t* hb = halo + (lz * s.XP + n) * 16;
         // software pipeline, two register sets: the operands of step st + 1 are requested before the 12 MFMAs of
         // step st issue; the halo offset of a step comes from registers (dz, dx advance by two kernel rows per step)
-        const int nst = (s.dbg & 2) ? 0 : s.nsteps;   // pairs of steps, then a lone one if odd
+        const int nst = SN_DBG(s, 2) ? 0 : s.nsteps;   // pairs of steps, then a lone one if odd
         int pdz = 0, pdx = (q >> 1);                 // kernel row p = 2 st + (q >> 1) of this lane group
         if (pdx >= s.kx) { pdx -= s.kx; ++pdz; }   // kx == 1
         const int hoff = (q & 1) * s.NRP * 16;   // the window's second chunk is one chunk plane further
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #undef SN_LIN_G
         // ---- epilogue: D[m = 4 q + i][n]: lane holds 4 consecutive y of row x0 + n
         const int gz = z0 + lz, gx = x0 + n;
-        const bool inside = gz < s.Z && gx < s.X && !(s.dbg & 4);
+        const bool inside = gz < s.Z && gx < s.X && !SN_DBG(s, 4);
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
         int rounds[KZMAX], total = 0;
 #pragma unroll
         for (int dz = 0; dz < KZMAX; ++dz) rounds[dz] = n[dz], total += n[dz];
-        const bool work = total > 0 && !(s.dbg & 1);   // no set voxel in reach of this delta tile: nothing to add
+        const bool work = total > 0 && !SN_DBG(s, 1);   // no set voxel in reach of this delta tile: nothing to add
         if (work) {
             __syncthreads();   // the previous job's gathers are done with the delta tile and the lists
             // ---- delta tile: rows q0 .. q0 + DR - 1 (zero outside the grid), columns ky - 1 - py + y
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kSpThreads, 6) void corr_gather_kernel(const DT* __
                 list_counts(nxt, nn);
             }
         }
-        if (work && !(s.dbg & 2)) {
+        if (work && !SN_DBG(s, 2)) {
             // every thread of a wave runs the same rounds (uniform trip counts: scalar loop control); the entries of the
             // next round are requested before this round's four reads
             const uint16_t* q = my_quads;

@@ -5,6 +5,7 @@ Each rank writes <out_dir>/rank<r>.json; the test process reads and compares the
 The training exchange under test is the reference's only multi-device hook, pl.Trainer(gpus=-1) (scripts/main.py:228):
 one rank per device, gradients of the ~50 scalars averaged across ranks every step."""
 import json
+import time
 import os
 import sys
 
@@ -71,6 +72,22 @@ def main():
     gathered = [torch.empty_like(vec) for _ in range(world)]
     dist.all_gather(gathered, vec)
     res["replicas_bit_identical"] = all(torch.equal(gathered[0], t) for t in gathered)
+
+    # ---- (c) latency of THE exchange of the training path: one all-reduce over the flat gradient vector
+    flat = torch.zeros(max(n_floats, 16), dtype=torch.float32, device=dev)
+    for _ in range(20):
+        dist.all_reduce(flat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_rep = 200
+    for _ in range(n_rep):
+        dist.all_reduce(flat)
+    torch.cuda.synchronize()
+    res["allreduce_flat_us"] = (time.perf_counter() - t0) / n_rep * 1e6
+    res["allreduce_floats"] = int(flat.numel())
+    res["env"] = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "MASTER_ADDR", "HIP_VISIBLE_DEVICES")}
+    res["device_name"] = torch.cuda.get_device_name(dev)
+    res["device_count"] = torch.cuda.device_count()
 
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)

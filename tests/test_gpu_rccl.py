@@ -30,7 +30,30 @@ def _launcher():
 def _run_worker(tmp_path, backend, extra):
     rc = _launcher().launch_ranks(2, WORKER, [str(tmp_path), backend, *extra], timeout_s=600)
     assert rc == 0, f"a rank failed (exit {rc})"
-    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    _leave_a_record(res, backend)
+    return res
+
+
+def _leave_a_record(res, backend):
+    """rccl_r04.json next to the pytest log (gpurun_out/ on a GPU box, else the working directory): ranks, devices, the IPC
+    mode in effect, the latency of the flat-gradient all-reduce -- so that a lease with >= 2 GPUs leaves something the next
+    reader can check, whoever ran it.  `backend` gloo = the one-GPU rehearsal, nccl = RCCL."""
+    out_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.getcwd()
+    rec = {"backend": backend, "is_rccl": backend == "nccl", "world": res[0]["world"],
+           "devices": [r["device"] for r in res], "device_count": res[0].get("device_count"),
+           "device_name": res[0].get("device_name"), "env": res[0].get("env"),
+           "allreduce_flat_us": [r.get("allreduce_flat_us") for r in res], "allreduce_floats": res[0].get("allreduce_floats"),
+           "replicas_bit_identical": [r["replicas_bit_identical"] for r in res], "two_graphs": [r["two_graphs"] for r in res],
+           "losses_rank0": res[0]["losses"]}
+    try:
+        path = os.path.join(out_dir, "rccl_r04.json")
+        prev = json.load(open(path)) if os.path.exists(path) else []
+        prev = prev if isinstance(prev, list) else [prev]
+        with open(path, "w") as f:
+            json.dump(prev + [rec], f, indent=1)
+    except OSError:
+        pass
 
 
 def _check(res, backend):
