@@ -281,13 +281,19 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         auto load_step24 = [&](int st, uint4 (&a)[3], uint4 (&xv)[4], int2& off) {
             const uint8_t* b0 = hb + off.x;
             const uint8_t* b1 = hb + off.y;
+            // (floor experiments, -DSN_CONV_DEBUG builds only, tools/debug/lin_floor.py: 32 = the A table is read for the
+            // first two steps only, 64 = the halo operands likewise -- the MFMAs then run on stale registers)
+            if (!(SN_DBG(s, 32) && st > 1)) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) a[d] = At[(st * 3 + d) * 64 + lane];
+                for (int d = 0; d < 3; ++d) a[d] = At[(st * 3 + d) * 64 + lane];
+            }
+            if (!(SN_DBG(s, 64) && st > 1)) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const uint2 lo = *reinterpret_cast<const uint2*>(b0 + v * cstride);
-                const uint2 hi = *reinterpret_cast<const uint2*>(b1 + v * cstride);
-                xv[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                for (int v = 0; v < 4; ++v) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(b0 + v * cstride);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(b1 + v * cstride);
+                    xv[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
             }
             off = *reinterpret_cast<const int2*>(offtab + 8 * (st + 2) + 2 * q);   // for this set's next use
         };

@@ -11,6 +11,8 @@ import scene_net_amd as sna
 from scene_net_amd import _hip
 from oracle import geneo_oracle as go
 
+from conftest import act_err_ok
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
@@ -73,9 +75,9 @@ def test_folded_equals_unfolded_and_oracle(hip_device, shape, G):
     assert _delta(c0, _hip.conv_i8_path_counts())[0] == 3 * groups   # the folded kernel was not even tried
     assert torch.equal(act_f, act_u) and torch.equal(out_f, out_u) and torch.equal(only_f, only_u)
     assert torch.equal(only_f, out_f)
-    assert (act_f.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item())
+    assert act_err_ok(act_f, ref_act, TOL)
     assert (out_f.cpu().double() - ref_out).abs().max().item() < TOL
-    assert (act_d.cpu() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item())
+    assert act_err_ok(act_d, ref_act, TOL)
     assert (out_d.cpu() - ref_out).abs().max().item() < TOL
 
 
@@ -99,7 +101,7 @@ def test_one_ulp_off_symmetry_takes_the_unfolded_kernel(hip_device):
             act_u, out_u = _run(x, b.to(hip_device), l)
         assert torch.equal(act, act_u) and torch.equal(out, out_u)
         ref = go.conv_bank(occ.double(), b.double().unsqueeze(1))
-        assert (act.cpu().double() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+        assert act_err_ok(act, ref, TOL)
 
 
 def test_geneo_banks_are_served_folded(hip_device):
@@ -120,7 +122,7 @@ def test_geneo_banks_are_served_folded(hip_device):
         act_u, out_u = _run(occ, bank, lam)
     assert torch.equal(act, act_u) and torch.equal(out, out_u)
     ref = go.conv_bank(occ.cpu().double(), bank.cpu().double().unsqueeze(1))
-    assert (act.cpu().double() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+    assert act_err_ok(act, ref, TOL)
 
 
 def test_guard_routes_a_symmetric_bank_it_cannot_serve(hip_device):
@@ -134,6 +136,7 @@ def test_guard_routes_a_symmetric_bank_it_cannot_serve(hip_device):
     served, declined, routed = _delta(c0, _hip.conv_i8_path_counts())
     assert (served, declined, routed) == (0, 0, 1)
     ref = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
+    # (routed to the fp32 matrix pipe: its accumulation error scales with the sum of |terms|, ~300 here: tensor-scale bar)
     assert (act.cpu().double() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
     fp32 = _hip.conv_bank(x.view(torch.uint8), b, l, want_act=True, want_out=True)
     assert torch.equal(act, fp32[0]) and torch.equal(out, fp32[1])
@@ -184,5 +187,5 @@ def test_random_shapes_folded_equals_unfolded(hip_device):
         assert torch.equal(act_f, act_u) and torch.equal(out_f, out_u), (case, (B, Z, X, Y, G))
         ref_act = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
         ref_out = torch.relu(torch.tanh((lam.double().view(1, G, 1, 1, 1) * ref_act).sum(1, keepdim=True)))
-        assert (act_f.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item()), case
+        assert act_err_ok(act_f, ref_act, TOL), case
         assert (out_f.cpu().double() - ref_out).abs().max().item() < TOL, case

@@ -11,6 +11,8 @@ import scene_net_amd as sna
 from scene_net_amd import _hip
 from oracle import geneo_oracle as go
 
+from conftest import act_err_ok
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 QMAX = 8355711.0   # 127 * (1 + 256 + 65536): the magnitude three balanced base-256 digits hold
@@ -227,7 +229,7 @@ def test_stride4_kernel_shapes_against_oracle_and_legacy(hip_device, shape, ks, 
         with legacy_kernel(legacy):
             for dt in (torch.float32, torch.float64):
                 act, out = _hip.conv_bank(x, b, l, want_act=True, want_out=True, out_dtype=dt)
-                assert (act.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item())
+                assert act_err_ok(act, ref_act, TOL)
                 assert (out.cpu().double() - ref_out).abs().max().item() < TOL
                 res[(legacy, dt)] = (act, out)
             _, only_out = _hip.conv_bank(x, b, l, want_act=False, want_out=True)

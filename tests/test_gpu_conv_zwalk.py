@@ -17,6 +17,8 @@ import scene_net_amd as sna
 from scene_net_amd import _hip
 from oracle import geneo_oracle as go
 
+from conftest import act_err_ok
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
@@ -84,7 +86,7 @@ def test_zwalk_equals_sn_conv_bank_and_oracle(hip_device, shape, G):
     assert torch.equal(only_z, only_r) and torch.equal(only_z, o_z)
     (a_d, o_d), (a_dr, o_dr) = _both(x, b, l, dt=torch.float64)
     assert torch.equal(a_d, a_dr) and torch.equal(o_d, o_dr)
-    assert (a_z.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item())
+    assert act_err_ok(a_z, ref_act, TOL)
     assert (o_z.cpu().double() - ref_out).abs().max().item() < TOL
     assert (o_d.cpu() - ref_out).abs().max().item() < TOL
     assert _hip.conv_i8_spin_timeouts() == _SPIN0
@@ -131,7 +133,7 @@ def test_zwalk_asymmetric_bank_runs_the_unfolded_body_in_the_same_launch(hip_dev
     assert _delta(c0, _hip.conv_i8_path_counts()) == (0, 2, 0)
     assert torch.equal(a_z, a_r) and torch.equal(o_z, o_r)
     ref = go.conv_bank(occ.double(), bank.double().unsqueeze(1))
-    assert (a_z.cpu().double() - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item())
+    assert act_err_ok(a_z, ref, TOL)
 
 
 def test_zwalk_guard_routes_a_wide_bank_to_fp32(hip_device):
@@ -319,7 +321,7 @@ def test_all_positive_and_zero_mean_banks_agree_in_every_int8_kernel(hip_device)
         for k, (a, o) in outs.items():
             assert torch.equal(a, a0) and torch.equal(o, o0), (name, k)
         assert (o0.cpu().double() - ref_out).abs().max().item() < TOL, name
-        assert (a0.cpu().double() - ref_act).abs().max().item() < TOL * max(1.0, ref_act.abs().max().item()), name
+        assert act_err_ok(a0, ref_act, TOL), name
 
 
 def test_verdict_is_learnt_without_a_sync_and_the_fallback_launch_left_out(hip_device):

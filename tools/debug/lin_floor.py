@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """K3L floor experiments (needs `make -B EXTRA=-DSN_CONV_DEBUG`; wrong results, timing only): SN_CONV_LIN_DBG bits 1 prologue
-only, 2 no MFMA loop, 4 no epilogue, 16 no deferral -- one process per setting (the switch is read per call in debug builds)."""
+only, 2 no MFMA loop, 4 no epilogue, 16 no deferral, 32 A table read for two steps only, 64 halo operands likewise -- one process per setting (the switch is read per call in debug builds)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import scene_net_amd as sna
@@ -13,7 +13,7 @@ model = sna.SceneNet(GENEO, (9, 9, 9)); apply_bank_spec(model, specs, names, lam
 batch = sna.PointBatch.from_tiles([synthetic_tile(t)[0] for t in range(32)], device=dev)
 x = sna.voxelize_batch(batch, (64, 64, 64), occ_dtype=torch.bool).occ
 bank, lam = model.compute_bank(dev), model.effective_lambdas(dev)
-for dbg in ((0, 16, 0, 16, 0, 16) if '--defer' in sys.argv else (0, 1, 2, 4, 6, 16)):
+for dbg in ((0, 16, 0, 16, 0, 16) if '--defer' in sys.argv else (0, 1, 2, 4, 6, 16, 32, 64, 96)):
     os.environ["SN_CONV_LIN_DBG"] = str(dbg)
     for _ in range(20): _hip.conv_fused(x, bank, lam)
     torch.cuda.synchronize()
