@@ -417,3 +417,44 @@ def test_size_mode_full_column_takes_the_exact_fallback(hip_device):
     want = vo.to_full_dense(vo.normalize_xyz(counts.astype(np.float64))) > 0
     assert np.array_equal(fast.occ[0, 0].cpu().numpy()[:nz, :nx, :ny], want)
     assert rows_empty == 0 and not np.array_equal(want, counts > 0)   # the case really differs from `count > 0`
+
+
+def test_one_pass_kernel_equals_the_two_kernel_form_on_many_ragged_tiles(hip_device):
+    """occ_onepass_kernel (round 4: the points stay in registers between the box pass and the binning; the tile's 16
+    workgroups exchange partial boxes inside the launch) against the two-kernel form it replaces (sn_set_option
+    "voxel_onepass", 0): the same descriptor, occupancy, tower plane, flags and dropped counts, bit for bit -- on more tiles
+    than the chip holds workgroups for at once (300 x 16 workgroups: the exchange's forward-progress argument at work), with
+    one- and two-point tiles, odd offsets and a tile beyond the register budget (117 111 points); and with K2 riding.
+    Reference: hist_on_voxel / reg_on_voxel, utils/voxelization.py:164-204, 244-300."""
+    rng = np.random.default_rng(3)
+    sizes = [int(s) for s in rng.integers(1, 4000, 296)] + [2, 1, 117_111, 60_001]   # (an empty tile is refused by PointBatch, as by the reference's numpy min())
+    tiles, labels = [], []
+    for t, n in enumerate(sizes):
+        xyz, lab = synthetic_tile(t % 40, max(n, 3))
+        tiles.append(xyz[:n]); labels.append(lab[:n])
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    outs = {}
+    for mode in (1, 0):
+        _hip.set_option("voxel_onepass", mode)
+        try:
+            plain = sna.voxelize_batch(batch, (64, 64, 64), [15, 16], want_occ=True, want_gt_occ=True, occ_dtype=torch.uint8)
+            head = sna.voxelize_batch(batch, (64, 64, 64), want_occ=True, occ_dtype=torch.bool)
+            rider = model.bank_rider(hip_device)
+            ridden = sna.voxelize_batch(batch, (64, 64, 64), want_occ=True, occ_dtype=torch.bool, bank_rider=rider)
+            torch.cuda.synchronize()
+            outs[mode] = (plain, head, ridden, rider[2].clone(), rider[3].clone())
+        finally:
+            _hip.set_option("voxel_onepass", 1)
+    (p1, h1, r1, bank1, prep1), (p0, h0, r0, bank0, prep0) = outs[1], outs[0]
+    live = torch.ones(len(sizes), dtype=torch.bool, device=hip_device)
+    for a, b in ((p1, p0), (h1, h0), (r1, r0)):
+        assert torch.equal(a.occ[live], b.occ[live]) and torch.equal(a.dropped[live], b.dropped[live])
+        assert torch.equal(a.flags[live], b.flags[live]) and torch.equal(a.desc[live], b.desc[live])
+    assert torch.equal(p1.gt_occ[live], p0.gt_occ[live])
+    assert torch.equal(bank1, bank0) and torch.equal(prep1, prep0) and r1.rider_done
+    assert torch.equal(bank1, model.compute_bank(hip_device))
+    assert _hip.device_status()[0] == 0
+    for b in (5, 297, 298, 299):                                     # and against the oracle
+        if sizes[b] > 1:
+            _check_tile(p1, b, tiles[b], labels[b], (64, 64, 64), [15, 16])
