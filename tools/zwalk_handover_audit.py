@@ -29,7 +29,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASM = os.path.join(ROOT, "build", "asm", "conv_i8s.s")
 SRC = [os.path.join(ROOT, "scene-net_amd", "csrc", f) for f in
-       ("conv_i8s.hip", "conv_i8z.inc", "conv_prep.h", "conv_fp32.inc", "common.h")]
+       ("conv_i8s.hip", "conv_i8_common.inc", "conv_i8s_kernel.inc", "conv_i8f.inc", "conv_i8z.inc", "conv_prep.h",
+        "conv_fp32.inc", "common.h")]
 # LDS carve-up of the walk (conv_i8z.inc): digit table, job table, scale / coefficients / bounds, counters, check table,
 # then the rings.  Offsets below kRawBase belong to tables and counters; ring and raw data start there.
 K_TABLES_END = 4 * 3 * 64 * 16 + 256 * 16 + 64 * 4 + 128 + 128 * 4 + 64 * 16   # = 18304 = 0x4780
