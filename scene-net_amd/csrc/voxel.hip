@@ -691,6 +691,11 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
 // Tiles with more than kOnePairs x 2 x 512 x 16 = 114 688 points: the surplus pairs are streamed from memory in both
 // phases, as the two-kernel form does.
 constexpr int kOnePairs = 7;
+#ifndef SN_ONE_THREADS
+#define SN_ONE_THREADS 1024
+#endif
+constexpr int kOneThreads = SN_ONE_THREADS;   // [measured, C2] 1024 threads x 8 parts per tile: stage 34.1 us; 512 x 16: 35.7-36.5 (half the partial bitmaps to write and to OR)
+constexpr int kOneParts = kOccParts * kOccThreads / kOneThreads;
 #ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/vox_timing.py
 __device__ unsigned long long g_vox_t[1024 * 8];   // per workgroup: 0 start, 1 points in + min/max, 2 published, 3 all tags seen, 4 descriptor, 5 binned, 6 end
 #define SN_VT(k) do { if (threadIdx.x == 0) g_vox_t[(blockIdx.y * gridDim.x + blockIdx.x) % 1024 * 8 + (k)] = wall_clock64(); } while (0)
@@ -700,7 +705,7 @@ __device__ unsigned long long g_vox_t[1024 * 8];   // per workgroup: 0 start, 1 
 constexpr unsigned long long kOneMagic = 0x5ce7e000ull << 32;
 
 template <bool kAligned>
-__global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* __restrict__ pts,
+__global__ __launch_bounds__(kOneThreads) void occ_onepass_kernel(const double* __restrict__ pts,
                                                                   const double* __restrict__ labels,
                                                                   const int64_t* __restrict__ offsets, int nx, int ny,
                                                                   int nz, int words, int planes, KeepLabels keep,
@@ -722,8 +727,8 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
     }
     __shared__ int dropped_blk;
     __shared__ double lohi[6];
-    __shared__ double red[kOccThreads / 64][6];
-    __shared__ double box16[kOccParts][6];
+    __shared__ double red[kOneThreads / 64][6];
+    __shared__ double box16[kOneParts][6];
     extern __shared__ double smem[];
     const int ne = nx + ny + nz + 3;
     double* edges = smem;
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
     long q0 = kAligned ? p0 + (p0 & 1) : p0;
     if (q0 > p1) q0 = p1;
     const long npair = (p1 - q0) >> 1;
-    const long gtid = (long)part * kOccThreads + tid, gstride = (long)kOccParts * kOccThreads;
+    const long gtid = (long)part * kOneThreads + tid, gstride = (long)kOneParts * kOneThreads;
     const double2* src = reinterpret_cast<const double2*>(pts + 3 * q0);
     double2 a[kOnePairs][3];
     unsigned kept = 0u;      // bit 2k / 2k + 1: the pair's first / second point carries a kept label (GT plane)
@@ -765,7 +770,7 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
         }
     }
     // (the bitmap is cleared while the loads are in flight)
-    for (int i = tid; i < words * planes; i += kOccThreads) bits[i] = 0u;
+    for (int i = tid; i < words * planes; i += kOneThreads) bits[i] = 0u;
     // the points that are nobody's pair: an odd first one (aligned form), an odd last one -- thread 0 of part 0
     const bool lone_first = kAligned && (p0 & 1) && p0 < p1, lone_last = ((p1 - q0) & 1) != 0;
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
@@ -808,11 +813,11 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
     __syncthreads();
     SN_VT(1);
     // ---- the exchange
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(box_parts) + (size_t)b * kOccParts * 8;
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(box_parts) + (size_t)b * kOneParts * 8;
     const unsigned long long tag = kOneMagic | epoch;
     if (tid < 6) {
         double v = red[0][tid];
-        for (int w = 1; w < kOccThreads / 64; ++w) v = (tid < 3) ? fmin(v, red[w][tid]) : fmax(v, red[w][tid]);
+        for (int w = 1; w < kOneThreads / 64; ++w) v = (tid < 3) ? fmin(v, red[w][tid]) : fmax(v, red[w][tid]);
         __hip_atomic_store(&slots[part * 8 + tid], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
         if (tid == 0) __hip_atomic_store(&slots[part * 8 + 6], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SN_VT(2);
-    if (tid < kOccParts) {
+    if (tid < kOneParts) {
         int spins = 0;
         while (__hip_atomic_load(&slots[tid * 8 + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
             if (++spins > (1 << 22)) {   // cannot happen (see "forward progress" above); never hang the GPU -- and never be
@@ -840,18 +845,18 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
     SN_VT(3);
     // (the boxes are read with agent-scope atomic loads, issued behind the tags' loads: no stale line of an earlier launch's
     // exchange can be taken for them, and no cache needs invalidating)
-    if (tid < kOccParts * 6)
+    if (tid < kOneParts * 6)
         box16[tid / 6][tid % 6] = __longlong_as_double((long long)__hip_atomic_load(
             &slots[(tid / 6) * 8 + tid % 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     __syncthreads();
     // the descriptor from the 16 partial boxes: derive_desc's own code on the LDS copy (same bits in every workgroup)
-    derive_desc(&box16[0][0], kOccParts, 0, nx, ny, nz, regular, lohi, edges, kOccThreads);
+    derive_desc(&box16[0][0], kOneParts, 0, nx, ny, nz, regular, lohi, edges, kOneThreads);
     if (part == 0) {
         double* dd = desc_out + (size_t)b * SN_DESC_LEN(nx, ny, nz);
-        for (int i = tid; i < 6 + ne; i += kOccThreads) dd[i] = (i < 6) ? lohi[i] : edges[i - 6];
+        for (int i = tid; i < 6 + ne; i += kOneThreads) dd[i] = (i < 6) ? lohi[i] : edges[i - 6];
         if (bbox_out && tid < 6) {
             double v = (tid < 3) ? DBL_MAX : -DBL_MAX;
-            for (int pp = 0; pp < kOccParts; ++pp) v = (tid < 3) ? fmin(v, box16[pp][tid]) : fmax(v, box16[pp][tid]);
+            for (int pp = 0; pp < kOneParts; ++pp) v = (tid < 3) ? fmin(v, box16[pp][tid]) : fmax(v, box16[pp][tid]);
             bbox_out[b * 6 + tid] = v;
         }
     }
@@ -887,15 +892,15 @@ __global__ __launch_bounds__(kOccThreads) void occ_onepass_kernel(const double* 
     }
     __syncthreads();
     SN_VT(5);
-    uint32_t* out = bits_ws + ((size_t)b * kOccParts + part) * (size_t)planes * words;
-    for (int i = tid; i < words; i += kOccThreads) {
+    uint32_t* out = bits_ws + ((size_t)b * kOneParts + part) * (size_t)planes * words;
+    for (int i = tid; i < words; i += kOneThreads) {
         out[i] = bits[i];
         if (want_tower) out[words + i] = bits[words + i];
     }
     if (dropped) atomicAdd(&dropped_blk, dropped);  // LDS
     __syncthreads();
     if (tid == 0) {
-        dropped_parts[b * kOccParts + part] = dropped_blk;
+        dropped_parts[b * kOneParts + part] = dropped_blk;
         if (flags && part == 0) flags[b] = 1;  // cleared by occ_finalize_kernel
     }
     SN_VT(6);
@@ -946,8 +951,8 @@ __global__ __launch_bounds__(kThreads) void occ_finalize_kernel(const uint32_t* 
     const int b = blockIdx.y;
     // (the one-pass kernel's exchange tags of this tile: zeroed here, behind that launch, so that a replayed graph --
     // whose launches carry the same tag every time -- never finds the previous replay's)
-    if (exchange_slots && blockIdx.x == 0 && threadIdx.x < kOccParts)
-        exchange_slots[((size_t)b * kOccParts + threadIdx.x) * 8 + 6] = 0ull;
+    if (exchange_slots && blockIdx.x == 0 && threadIdx.x < parts)
+        exchange_slots[((size_t)b * parts + threadIdx.x) * 8 + 6] = 0ull;
     if (dropped && blockIdx.x == 0 && threadIdx.x == 0) {
         int t = 0;
         for (int p = 0; p < parts; ++p) t += dropped_parts[b * parts + p];
@@ -1432,7 +1437,7 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
         return sn::fail(SN_ERR_UNSUPPORTED,
                         "sn_voxel_occupancy: %zu voxels x %d planes do not fit the LDS bitmap in <= %d z-slabs "
                         "(use sn_voxel_scatter + sn_voxel_finalize)", V, planes, kOccParts);
-    const int parts = kOccParts / slabs;
+    const int parts = onepass ? kOneParts : kOccParts / slabs;   // (eligibility of the one-pass form implies slabs == 1)
     if (gt_occ && flags && counts_ws && !towers_ws)
         return sn::fail(SN_ERR_INVALID_ARG, "sn_voxel_occupancy: the counting fallback needs towers_ws for gt_occ");
     const int words = (int)(V / 32);
@@ -1451,13 +1456,13 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
         const unsigned epoch = epoch_ctr.fetch_add(1, std::memory_order_relaxed) + 1;
         BankRider none{};
         const BankRider& r = onepass_rider ? *onepass_rider : none;
-        const int rider_rows = onepass_rider ? (r.nblocks + kOccParts - 1) / kOccParts : 0;
+        const int rider_rows = onepass_rider ? (r.nblocks + kOneParts - 1) / kOneParts : 0;
         exchange = reinterpret_cast<unsigned long long*>(const_cast<double*>(box_parts));
         const bool al_p = aligned16(pts);
         auto kern = al_p ? occ_onepass_kernel<true> : occ_onepass_kernel<false>;
         if (sn::ensure_dynamic_lds((const void*)kern, 96 * 1024) != hipSuccess)
             return sn::check_launch("sn_voxel_occupancy_fused(hipFuncSetAttribute)");
-        hipLaunchKernelGGL(kern, dim3(kOccParts, B + rider_rows), dim3(kOccThreads), lds1, s, pts, labels, offsets, nx, ny, nz,
+        hipLaunchKernelGGL(kern, dim3(kOneParts, B + rider_rows), dim3(kOneThreads), lds1, s, pts, labels, offsets, nx, ny, nz,
                            words, planes, keep, bits_ws, dropped_parts, flags, const_cast<double*>(box_parts), epoch, regular,
                            desc, bbox_out, sn::sticky_device_ptr(), rider_rows, r);
     } else {

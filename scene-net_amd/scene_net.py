@@ -52,6 +52,18 @@ class _TrackedParameter(nn.Parameter):
         return nn.Parameter.__repr__(self.as_subclass(nn.Parameter))   # prints like the nn.Parameter it stands for
 
 
+# torch's optimisers take their multi-tensor ("foreach" / fused) paths only for parameters whose exact type is on a list of
+# two -- torch.Tensor and nn.Parameter; any other type drops them to one tiny kernel per parameter and operation
+# ([measured] round 4: the captured training step 0.225 -> 0.309 ms, 14 extra elementwise launches per step, the moment
+# the parameters carried the subclass).  The subclass adds a Python property and nothing a foreach kernel can see.
+try:
+    from torch.optim import optimizer as _torch_optimizer
+    if _TrackedParameter not in _torch_optimizer._foreach_supported_types:
+        _torch_optimizer._foreach_supported_types.append(_TrackedParameter)
+except (ImportError, AttributeError):   # a torch without that list: the optimiser still works, one kernel per parameter
+    pass
+
+
 def _track(p):
     """tags a Parameter so that its `.data` accesses are counted (a class swap: same object, same storage)"""
     if type(p) is nn.Parameter:
@@ -62,6 +74,16 @@ def _track(p):
 def _set_data_untracked(p, value) -> None:
     """p.data = value from inside this module (the flat buffer's aliasing): not a user write"""
     _TENSOR_DATA.__set__(p, value)
+
+
+class _RiderOutputs(tuple):
+    """(bank, lam) of SceneNet.train_rider() -- still a 2-tuple for callers that unpack it -- with the buffer set's identity
+    and generation, so that the forward can tell its backward which buffers it read (see train_rider)."""
+
+    def __new__(cls, pair, ring, k, gen):
+        self = super().__new__(cls, pair)
+        self.ring, self.k, self.gen = ring, k, gen
+        return self
 
 
 class _LivePack:
@@ -354,15 +376,25 @@ class SceneNet(nn.Module):
         flat, meta, _ = self._flat_sync(device)
         G = meta["G"]
         n = G * _hip.SN_NPARAM
-        bufs = self.__dict__.get("_train_rider_bufs")
-        if bufs is None or bufs[0].device != device or bufs[0].shape[0] != G:
-            bufs = (torch.empty((G, 9, 9, 9), dtype=torch.float32, device=device),
-                    torch.zeros(_hip.SN_CONV_PREP_BYTES * ((G + 15) // 16), dtype=torch.uint8, device=device),
-                    torch.empty(G, dtype=torch.float32, device=device))
-            self.__dict__["_train_rider_bufs"] = bufs
-        bank, prep, lam = bufs
+        # The rider writes (bank, lam) through raw pointers into buffers the model keeps -- no allocation per step -- and the
+        # forward saves them for its backward.  A LATER rider launch would rewrite them in place with no version bump, so
+        # autograd's saved-tensor check could not see it.  Two buffer sets, used alternately, each with a
+        # generation number: the backward of a forward whose set has been handed out again since raises instead of reading
+        # another step's bank.  (One forward may overlap -- a validation pass with grad enabled, retain_graph; a third
+        # before the first one's backward is refused loudly.)  No copy, no launch.
+        ring = self.__dict__.get("_train_rider_bufs")
+        if ring is None or ring["sets"][0][0].device != device or ring["sets"][0][0].shape[0] != G:
+            ring = {"sets": [(torch.empty((G, 9, 9, 9), dtype=torch.float32, device=device),
+                              torch.zeros(_hip.SN_CONV_PREP_BYTES * ((G + 15) // 16), dtype=torch.uint8, device=device),
+                              torch.empty(G, dtype=torch.float32, device=device)) for _ in range(2)],
+                    "gen": [0, 0], "next": 0}
+            self.__dict__["_train_rider_bufs"] = ring
+        k = ring["next"]
+        ring["next"] = 1 - k
+        ring["gen"][k] += 1
+        bank, prep, lam = ring["sets"][k]
         rider = (flat[:n].view(G, _hip.SN_NPARAM), meta["kinds"], bank, prep, flat[n:], meta["order"], meta["last"], lam)
-        return rider, (bank, lam)
+        return rider, _RiderOutputs((bank, lam), ring, k, ring["gen"][k])
 
     def contract_prepared(self, x: torch.Tensor, bank: torch.Tensor, lam: torch.Tensor, prep: torch.Tensor,
                           want_act: bool = False, out_dtype: Optional[torch.dtype] = None):
@@ -521,15 +553,11 @@ class _GeneoForwardFn(torch.autograd.Function):
         G = meta["G"]
         n = G * _hip.SN_NPARAM
         p = flat[:n].view(G, _hip.SN_NPARAM)
+        ctx.rider_guard = None
         if bank_lam is not None:   # (SceneNet.train_rider: the same kernels' code ran in the voxelisation's first launch)
             bank, lam = bank_lam
-            if not torch.cuda.is_current_stream_capturing():
-                # the rider's buffers are the model's persistent ones, rewritten in place by the NEXT rider launch through a
-                # raw pointer (no version bump, so autograd's saved-tensor check cannot see it): a second forward before this
-                # graph's backward -- gradient accumulation, retain_graph, an eval pass with grad enabled -- would make the
-                # backward read the other step's bank.  Eagerly the step keeps its own copy (46 KB + G floats); a captured
-                # step is forward -> backward inside one graph and needs none.
-                bank, lam = bank.clone(), lam.clone()
+            if isinstance(bank_lam, _RiderOutputs):
+                ctx.rider_guard = (bank_lam.ring, bank_lam.k, bank_lam.gen)   # checked by backward
         else:
             bank, lam = _hip.geneo_bank_lambdas(p, meta["kinds"], kernel_size, flat[n:], meta["order"], meta["last"])
         out_dtype = x.dtype if x.dtype in (torch.float32, torch.float64) else torch.float32
@@ -551,6 +579,14 @@ class _GeneoForwardFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, _gact=None):
         x, out, bank, P, lam, kinds = ctx.saved_tensors
+        if ctx.rider_guard is not None:
+            ring, k, gen = ctx.rider_guard
+            if ring["gen"][k] != gen:
+                raise RuntimeError(
+                    "SceneNet backward: the bank / coefficient buffers this forward was given by train_rider() have been "
+                    "handed to a later forward since (they are persistent and rewritten in place by the voxelisation's "
+                    "rider): more than one other train_rider() forward ran before this backward.  Run the backward first, "
+                    "or call forward without bank_lam (the forward then builds its own bank).")
         G = ctx.G
         n = G * _hip.SN_NPARAM
         # bf16 activations stay bf16 (half the bytes of the two grids this pass reads; products and sums are fp32)

@@ -349,3 +349,40 @@ def test_fused_criterion_equals_its_parts(hip_device, crit_cls, bf16):
     assert grads_f.keys() == grads_p.keys() and len(grads_f) > 10
     for n in grads_f:
         assert torch.equal(grads_f[n], grads_p[n]), n
+
+
+def test_rider_buffers_are_guarded_against_a_later_forward(hip_device):
+    """train_rider()'s (bank, lam) live in persistent buffers the NEXT rider launch rewrites in place (no version
+    bump for autograd to see).  Two sets are used alternately: one other forward may run before a backward (same gradients
+    as without it); after a second one the first graph's backward raises instead of reading another step's bank."""
+    from scene_net_amd.synthetic import synthetic_tile
+    from scene_net_amd.training import voxelize_and_forward
+    tiles, labels = zip(*[synthetic_tile(t, 20_000) for t in range(2)])
+    torch.manual_seed(3)
+    model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
+    pipe = sna.ScenePipeline(model, (32, 32, 32), keep_labels=[15.0])
+    assert pipe.rides(2)
+
+    def grads_after(n_other_forwards):
+        model.zero_grad(set_to_none=True)
+        g, out = voxelize_and_forward(pipe, batch)
+        keep = []
+        for _ in range(n_other_forwards):
+            with torch.no_grad():
+                next(iter(model.geneos.values())).geneo_params["radius"].add_(0.01)   # the other steps see other parameters
+            keep.append(voxelize_and_forward(pipe, batch))
+        out.float().sum().backward()
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    g0 = grads_after(0)
+    with torch.no_grad():
+        next(iter(model.geneos.values())).geneo_params["radius"].sub_(0.0)
+    torch.manual_seed(3)
+    model2 = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
+    pipe2 = sna.ScenePipeline(model2, (32, 32, 32), keep_labels=[15.0])
+    model, pipe = model2, pipe2
+    g1 = grads_after(1)          # one overlapping forward (with changed parameters): the first graph still reads ITS bank
+    assert set(g0) == set(g1) and all(torch.equal(g0[n], g1[n]) for n in g0)
+    with pytest.raises(RuntimeError, match="handed to a later forward"):
+        grads_after(2)
