@@ -1,7 +1,7 @@
 # Copies one evidence run (gpurun_out/<tag>/, written by tools/round_run.sh) into profiles/<tag>_* (tracked):
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 S=gpurun_out/$TAG
 P=profiles
 cp $S/bench.json $P/${TAG}_bench.json
@@ -19,7 +19,8 @@ cp $S/train_kernel_stats.csv $P/${TAG}_train_kernel_stats.csv
 cp $S/step_host.txt $P/${TAG}_step_host.txt
 cp $S/k1_time.txt $P/${TAG}_k1_time.txt
 cp $S/corr_time.txt $P/${TAG}_corr_time.txt
-cp $S/zwalk_repeat.txt $P/${TAG}_zwalk_repeat.txt
+cp $S/ldsdma_handover.txt $P/${TAG}_ldsdma_handover.txt
+[ -f gpurun_out/rccl_r04.json ] && cp gpurun_out/rccl_r04.json $P/${TAG}_rccl_record.json || true
 tail -3 $S/pytest_gpu.txt > $P/${TAG}_pytest_gpu_tail.txt
 python3 tools/traffic_json.py $S/pmc_traffic.csv $P/traffic.json ${TAG}_pmc_traffic.csv --keep-missing
 echo collected
