@@ -107,6 +107,11 @@ int sn_device_count(void);
  *       instead of the stride-4 kernel (conv_i8s.hip) it prefers for ky = 9 (A/B timing, parity tests of both).
  *   "conv_i8z_variant" (default 2): the shape of the z-walk's tickets -- 0: rounds of two x-rows on 8 waves, 1: one round of
  *       one x-row per ticket on 12 waves, 2: two such rounds per ticket.  Same results bit for bit (tested on all three).
+ *   "voxel_onepass" (default 1): sn_voxel_occupancy_fused[_bank] on grids whose bitmap(s) fit one workgroup's LDS (64^3)
+ *       read the points ONCE -- bounding box, descriptor and binning in one launch whose workgroups exchange partial boxes;
+ *       0 = the two-kernel form (box pass, then binning pass).  Same results bit for bit.
+ *   "voxel_onepass_spin" (default 64): polls (~1 us each) a workgroup of that launch waits for its tile's other workgroups
+ *       before it computes the tile's box from the points alone (same bits; 0 = never wait).
  *   "conv_i8z_inject_fault" (default 0): TEST HOOK.  1 = the next z-walk launches never report plane 0's first raw rows
  *       as landed, so a dependency spin gives up (~0.5 s per launch): the way to see the loud failure path -- NaN outputs
  *       and the sticky device status -- on the product build (tests/test_gpu_conv_zwalk.py). */

@@ -27,6 +27,8 @@ int option_conv_i8_legacy() {
 }
 static std::atomic<int> g_vox_onepass{1};
 int option_voxel_onepass() { return g_vox_onepass.load(std::memory_order_relaxed); }
+static std::atomic<int> g_vox_spin{64};
+int option_voxel_onepass_spin() { return g_vox_spin.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8z_fault{0};
 int option_conv_i8z_inject_fault() { return g_i8z_fault.load(std::memory_order_relaxed); }
 static std::atomic<int> g_i8z_variant{2};
@@ -150,12 +152,11 @@ int sticky_check(const char* what) {
         static const char* const kText[] = {"", "a dependency spin of the z-walk contraction gave up (its workgroup's outputs are NaN)",
                                             "a launch made with `assume served` was declined by the bank's guard (its outputs are NaN): "
                                             "a cached verdict did not belong to these parameters",
-                                            "a hand-over spin of an int8 tile kernel gave up (that launch's output is not to be trusted)",
-                                            "the box exchange of the one-pass voxelisation gave up (that tile's grid is not to be trusted)"};
+                                            "a hand-over spin of an int8 tile kernel gave up (that launch's output is not to be trusted)"};
         const int code = w[0];
         return fail(SN_ERR_DEVICE_STATUS, "%s: device %d has a latched status %d -- %s [workgroup %d, detail %d]; "
                     "sn_device_status_clear() re-arms the device", what, dev, code,
-                    (code >= 1 && code <= 4) ? kText[code] : "unknown", (int)w[2], (int)w[3]);
+                    (code >= 1 && code <= 3) ? kText[code] : "unknown", (int)w[2], (int)w[3]);
     }
     return SN_OK;
 }
@@ -211,6 +212,11 @@ extern "C" int sn_set_option(const char* name, int value) {
         sn::g_vox_onepass.store(value ? 1 : 0, std::memory_order_relaxed);
         return SN_OK;
     }
+    if (strcmp(name, "voxel_onepass_spin") == 0) {
+        if (value < 0) return sn::fail(SN_ERR_INVALID_ARG, "sn_set_option: voxel_onepass_spin must be >= 0");
+        sn::g_vox_spin.store(value, std::memory_order_relaxed);
+        return SN_OK;
+    }
     if (strcmp(name, "conv_i8z_inject_fault") == 0) {
         sn::g_i8z_fault.store(value ? 1 : 0, std::memory_order_relaxed);
         return SN_OK;
@@ -242,6 +248,7 @@ extern "C" int sn_get_option(const char* name) {
     if (name && strcmp(name, "conv_i8z_variant") == 0) return sn::option_conv_i8z_variant();
     if (name && strcmp(name, "conv_i8z_inject_fault") == 0) return sn::option_conv_i8z_inject_fault();
     if (name && strcmp(name, "voxel_onepass") == 0) return sn::option_voxel_onepass();
+    if (name && strcmp(name, "voxel_onepass_spin") == 0) return sn::option_voxel_onepass_spin();
     if (name && strcmp(name, "corr_sparse_tile_bytes") == 0) return sn::option_corr_sparse_tile_bytes();
     if (name)
         for (int i = 0; i < sn::kOptCount; ++i)

@@ -31,6 +31,7 @@ inline hipStream_t as_stream(sn_stream_t s) { return reinterpret_cast<hipStream_
 int option_conv_skip_empty_tiles();  // cabi.hip (sn_set_option)
 int option_conv_i8_fold();            // cabi.hip (sn_set_option "conv_i8_fold", default 1): 0 = never try the folded int8 kernel (conv_i8s.hip)
 int option_voxel_onepass();           // cabi.hip (sn_set_option "voxel_onepass", default 1): 0 = the two-kernel form (bbox, then binning) on every grid
+int option_voxel_onepass_spin();      // cabi.hip (sn_set_option "voxel_onepass_spin", default 64): polls of the box exchange before a workgroup goes alone
 int option_conv_i8z_inject_fault();   // cabi.hip (sn_set_option "conv_i8z_inject_fault"): test hook, see conv_i8z.inc's prologue
 int option_conv_i8z_variant();        // cabi.hip (sn_set_option "conv_i8z_variant"): shape of the z-walk kernel's rounds (conv_i8z.inc)
 int option_corr_sparse_tile_bytes();  // cabi.hip (sn_set_option "corr_sparse_tile_bytes"): input bytes per job of the sparse correlation (0: 2048, the maximum)

@@ -687,7 +687,9 @@ __global__ __launch_bounds__(kOccThreads) void occ_partial_kernel(const double* 
 // epoch at every replay) starts clean each time.
 // Forward progress: a workgroup publishes before it waits, and waits only for workgroups of ITS tile.  Each XCD is handed
 // its share of the grid in order (tile-major: blockIdx.y = tile), so the lowest unfinished tile always has every workgroup
-// dispatched or about to be; at C2 (16 x 32 workgroups, two per CU) the whole grid is resident at once.
+// dispatched or about to be; at C2 (8 x 32 workgroups of 1024 threads, one per CU) the whole grid is resident at once.
+// And the wait is bounded: after `spin_max` polls a workgroup computes the tile's box from the points alone (same bits) --
+// so the launch cannot hang or go wrong even where that argument does not hold (grids of two processes interleaved).
 // Tiles with more than kOnePairs x 2 x 512 x 16 = 114 688 points: the surplus pairs are streamed from memory in both
 // phases, as the two-kernel form does.
 constexpr int kOnePairs = 7;
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(kOneThreads) void occ_onepass_kernel(const double* 
                                                                   int32_t* __restrict__ flags,
                                                                   double* __restrict__ box_parts, unsigned epoch,
                                                                   int regular, double* __restrict__ desc_out,
-                                                                  double* __restrict__ bbox_out, int32_t* sticky,
+                                                                  double* __restrict__ bbox_out, int spin_max,
                                                                   int rider_rows, BankRider r) {
     if ((int)blockIdx.y < rider_rows) {
         // K2 as riders (the first grid rows: dispatched first), 256 of the 512 threads build kernel g + its preparation
@@ -831,23 +833,63 @@ __global__ __launch_bounds__(kOneThreads) void occ_onepass_kernel(const double* 
         if (tid == 0) __hip_atomic_store(&slots[part * 8 + 6], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     SN_VT(2);
+    // The wait is BOUNDED and nobody depends on its outcome: a workgroup whose siblings have not all published after
+    // `spin_max` polls (~1 us each) stops waiting and takes the tile's box from the points itself (one streaming pass over
+    // the whole tile: min / max are exact and order-free, so it gets the very bits the exchange would have delivered).
+    // In-order dispatch makes that a path for pathological cases only -- two processes' grids interleaved on one GPU can
+    // leave each other's workgroups without the slots their siblings need -- but it means the launch can neither hang nor
+    // compute a wrong box, whatever shares the device (spin_max 0: never wait; tested).
+    bool gave_up = false;
     if (tid < kOneParts) {
         int spins = 0;
         while (__hip_atomic_load(&slots[tid * 8 + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-            if (++spins > (1 << 22)) {   // cannot happen (see "forward progress" above); never hang the GPU -- and never be
-                sn::sticky_latch(sticky, 4, b, part);   // quiet about it: the tile's box, hence its grid, would be wrong
-                break;
-            }
+            if (++spins > spin_max) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(4);
         }
     }
-    __syncthreads();
+    const bool alone = __syncthreads_or(gave_up ? 1 : 0) != 0;
     SN_VT(3);
-    // (the boxes are read with agent-scope atomic loads, issued behind the tags' loads: no stale line of an earlier launch's
-    // exchange can be taken for them, and no cache needs invalidating)
-    if (tid < kOneParts * 6)
-        box16[tid / 6][tid % 6] = __longlong_as_double((long long)__hip_atomic_load(
-            &slots[(tid / 6) * 8 + tid % 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (!alone) {
+        // (the boxes are read with agent-scope atomic loads, issued behind the tags' loads: no stale line of an earlier
+        // launch's exchange can be taken for them, and no cache needs invalidating)
+        if (tid < kOneParts * 6)
+            box16[tid / 6][tid % 6] = __longlong_as_double((long long)__hip_atomic_load(
+                &slots[(tid / 6) * 8 + tid % 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else {
+        double m2[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, x2[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (long i = p0 + tid; i < p1; i += kOneThreads) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double v = pts[3 * i + c];
+                m2[c] = fmin(m2[c], v);
+                x2[c] = fmax(x2[c], v);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                m2[c] = fmin(m2[c], __shfl_xor(m2[c], o, 64));
+                x2[c] = fmax(x2[c], __shfl_xor(x2[c], o, 64));
+            }
+        }
+        __syncthreads();   // (red[] was read by the publishing threads above)
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                red[tid >> 6][c] = m2[c];
+                red[tid >> 6][3 + c] = x2[c];
+            }
+        }
+        __syncthreads();
+        if (tid < kOneParts * 6) {
+            const int c = tid % 6;
+            double v = (c < 3) ? DBL_MAX : -DBL_MAX;          // parts 1.. are neutral; part 0 carries the tile's box
+            if (tid < 6)
+                for (int w = 0; w < kOneThreads / 64; ++w) v = (c < 3) ? fmin(v, red[w][c]) : fmax(v, red[w][c]);
+            box16[tid / 6][c] = v;
+        }
+    }
     __syncthreads();
     // the descriptor from the 16 partial boxes: derive_desc's own code on the LDS copy (same bits in every workgroup)
     derive_desc(&box16[0][0], kOneParts, 0, nx, ny, nz, regular, lohi, edges, kOneThreads);
@@ -1464,7 +1506,7 @@ static int occupancy_impl(const double* pts, const double* labels, const int64_t
             return sn::check_launch("sn_voxel_occupancy_fused(hipFuncSetAttribute)");
         hipLaunchKernelGGL(kern, dim3(kOneParts, B + rider_rows), dim3(kOneThreads), lds1, s, pts, labels, offsets, nx, ny, nz,
                            words, planes, keep, bits_ws, dropped_parts, flags, const_cast<double*>(box_parts), epoch, regular,
-                           desc, bbox_out, sn::sticky_device_ptr(), rider_rows, r);
+                           desc, bbox_out, sn::option_voxel_onepass_spin(), rider_rows, r);
     } else {
         auto kern = al ? occ_partial_kernel<true> : occ_partial_kernel<false>;
         if (sn::ensure_dynamic_lds((const void*)kern, 96 * 1024) != hipSuccess)

@@ -435,8 +435,9 @@ def test_one_pass_kernel_equals_the_two_kernel_form_on_many_ragged_tiles(hip_dev
     batch = sna.PointBatch.from_tiles(tiles, labels, device=hip_device)
     model = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9)).to(hip_device)
     outs = {}
-    for mode in (1, 0):
-        _hip.set_option("voxel_onepass", mode)
+    for mode in (1, 0, 2):         # 2: the one-pass form with the exchange's wait at zero -- every workgroup goes alone
+        _hip.set_option("voxel_onepass", 1 if mode else 0)
+        _hip.set_option("voxel_onepass_spin", 0 if mode == 2 else 64)
         try:
             plain = sna.voxelize_batch(batch, (64, 64, 64), [15, 16], want_occ=True, want_gt_occ=True, occ_dtype=torch.uint8)
             head = sna.voxelize_batch(batch, (64, 64, 64), want_occ=True, occ_dtype=torch.bool)
@@ -446,6 +447,10 @@ def test_one_pass_kernel_equals_the_two_kernel_form_on_many_ragged_tiles(hip_dev
             outs[mode] = (plain, head, ridden, rider[2].clone(), rider[3].clone())
         finally:
             _hip.set_option("voxel_onepass", 1)
+            _hip.set_option("voxel_onepass_spin", 64)
+    for a, b in zip(outs[2][:3], outs[1][:3]):
+        assert torch.equal(a.occ, b.occ) and torch.equal(a.desc, b.desc) and torch.equal(a.flags, b.flags)
+    assert torch.equal(outs[2][0].gt_occ, outs[1][0].gt_occ)
     (p1, h1, r1, bank1, prep1), (p0, h0, r0, bank0, prep0) = outs[1], outs[0]
     live = torch.ones(len(sizes), dtype=torch.bool, device=hip_device)
     for a, b in ((p1, p0), (h1, h0), (r1, r0)):
