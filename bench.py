@@ -532,7 +532,7 @@ def main():
         g_ms = (time.perf_counter() - ts) / args.steps * 1e3
         graph_info = {"ms_per_step": g_ms, "tiles_per_s_per_gpu": B / (g_ms * 1e-3),
                       "identical_output": bool(torch.equal(out_graph, out)),
-                      "note": "whole step (4 voxel launches, the bank + preparation riding in the first; conv) replayed "
+                      "note": "whole step (3 voxel launches -- one pass over the points with the bank + preparation riding in it, finalize, gated fallback --; conv) replayed "
                               "from one hipGraph"}
         del graph
         if fused_info is not None:   # the 0.12 ms fused step is at the edge of being host bound when launched eagerly
@@ -636,8 +636,8 @@ def main():
                           "unit": "TFLOP/s", "frac": conv32_tflops / PEAK_F32_MFMA_TFLOPS,
                           "traffic": traffic.get("conv_bank_kernel"), "launch_ms": conv32_ms,
                           "flops_per_launch": conv_flops, "tiles_per_s_conv_only": B / (conv32_ms * 1e-3)},
-        "roofline_voxel": {"kernel": "K1: bbox partials + (descriptor derived in-kernel) LDS-bitmap occupancy + finalize + "
-                                     "gated fallback (4 launches)", "bound": "hbm", "achieved": vox_gbs, "peak": PEAK_HBM_GBS,
+        "roofline_voxel": {"kernel": "K1: one pass over the points (box, in-launch exchange, descriptor, LDS-bitmap occupancy; K2 riding) + "
+                                     "finalize + gated fallback (3 launches at 64^3; larger grids: box pass + z-slab binning, 4)", "bound": "hbm", "achieved": vox_gbs, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": vox_gbs / PEAK_HBM_GBS, "traffic": traffic.get("voxel_stage"),
                            "stage_ms": vox_ms, "stages_timed": len(vox_ev), "bytes_per_stage": vox_bytes},
         "fused_linear": fused_info,
