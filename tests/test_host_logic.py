@@ -237,7 +237,7 @@ def test_scene_net_picks_the_linear_forward_only_for_what_it_serves():
     assert sna.SceneNet.fused_forward is True
 
 
-@pytest.mark.parametrize("name", ["r01_final_bench.json", "r02_bench.json", "r03_bench.json"])
+@pytest.mark.parametrize("name", ["r01_final_bench.json", "r02_bench.json", "r03_bench.json", "r04_bench.json"])
 def test_committed_bench_line_keeps_the_contract(name):
     """profiles/<name> (stdout of bench.py on the MI355X box) carries every key the driver's contract names, the roofline
     and CPU-baseline objects, and internally consistent figures (round 2 adds the fp32 and cold figures and the ranks)."""
@@ -263,7 +263,13 @@ def test_committed_bench_line_keeps_the_contract(name):
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    if name.startswith("r03"):   # round 3: the sustained figure, and the dominant kernel is the z-walk
+    if name.startswith("r04"):   # round 4: the sustained loop is long enough for an outside sampler and carries the device's own
+        busy = d["sustained"]["gpu_busy_percent"]   # busy counter; the voxel stage is the one-pass form; the reference's defaults
+        assert d["sustained"]["wall_s"] >= 5.0 and busy["samples"] >= 20 and busy["frac_samples_busy_ge_90"] >= 0.9
+        assert "one pass" in d["roofline_voxel"]["kernel"] and d["roofline_voxel"]["traffic"] < 1.6 * d["roofline_voxel"]["bytes_per_stage"]
+        rd = d["reference_defaults"]
+        assert rd["head_only"]["ms_per_call"] > 0 and "K3L" in rd["head_only"]["kernel"] and rd["bound"].startswith("hbm")
+    if name.startswith(("r03", "r04")):   # round 3: the sustained figure, and the dominant kernel is the z-walk
         assert d["value_sustained"] >= d["value"] and "conv_occ_i8z_kernel" in r["kernel"] and r["launches_timed"] >= 3
         assert abs(d["sustained"]["value"] - tiles / (d["sustained"]["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
