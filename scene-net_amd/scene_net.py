@@ -48,8 +48,9 @@ class _TrackedParameter(nn.Parameter):
         _DATA_TOUCHES[0] += 1
         _TENSOR_DATA.__set__(self, value)
 
-    def __repr__(self):
-        return nn.Parameter.__repr__(self.as_subclass(nn.Parameter))   # prints like the nn.Parameter it stands for
+    def __repr__(self):   # prints like the nn.Parameter it stands for
+        t = torch.Tensor.detach(self).as_subclass(torch.Tensor)
+        return "Parameter containing:\n" + repr(t.requires_grad_(self.requires_grad))
 
 
 # torch's optimisers take their multi-tensor ("foreach" / fused) paths only for parameters whose exact type is on a list of

@@ -322,3 +322,46 @@ def test_round3_entry_points_are_bound():
     assert int(lib.sn_conv_fused_prep_bytes(9, 9, 9)) > 0 and int(lib.sn_conv_fused_prep_bytes(9, 9, 40)) == 0
     assert int(lib.sn_conv_corr_ws_bytes(_hip.SN_OCC8, 32, 64, 64, 64, 9, 9, 9)) > \
         int(lib.sn_conv_corr_ws_bytes(_hip.SN_F32, 32, 64, 64, 64, 9, 9, 9)) > 0
+
+
+def test_tracked_parameters_stay_ordinary_parameters():
+    """The model's parameters carry a Parameter subclass that counts `.data` accesses (scene_net._TrackedParameter: the caches
+    see a write through .data).  It must change nothing a user of nn.Parameter can observe: isinstance, repr, state_dict keys
+    and values, deepcopy (keeps the subclass), pickle (comes back a plain Parameter and is re-tagged lazily), optimisers on
+    torch's multi-tensor path; and `.data` reads / writes / assignments bump the touch counter the cache keys carry."""
+    import copy
+    import io
+    from scene_net_amd import scene_net as sn
+    m = sna.SceneNet({"cy": 2, "cone": 1, "neg": 1}, (9, 9, 9))
+    plain_repr = {n: repr(p) for n, p in m.named_parameters()}
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    for p in m.parameters():
+        sn._track(p)
+    assert all(type(p) is sn._TrackedParameter and isinstance(p, torch.nn.Parameter) for p in m.parameters())
+    assert {n: repr(p) for n, p in m.named_parameters()} == plain_repr
+    assert list(m.state_dict()) == list(sd0) and all(torch.equal(m.state_dict()[k], sd0[k]) for k in sd0)
+    assert all(type(p) is sn._TrackedParameter for p in copy.deepcopy(m).parameters())
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert all(isinstance(p, torch.nn.Parameter) for p in m2.parameters())
+    m2.load_state_dict(m.state_dict())
+    from torch.optim import optimizer as topt
+    assert sn._TrackedParameter in topt._foreach_supported_types
+    p = next(q for q in m.parameters() if q.requires_grad)
+    t0, v0 = sn._DATA_TOUCHES[0], p._version
+    p.data.add_(0.5)
+    assert sn._DATA_TOUCHES[0] == t0 + 1 and p._version == v0          # invisible to _version, counted here
+    p.data = p.data.clone()
+    assert sn._DATA_TOUCHES[0] >= t0 + 3
+    t1 = sn._DATA_TOUCHES[0]
+    with torch.no_grad():
+        p.add_(1.0)                                                     # an ordinary in-place op: version, not the counter
+    assert sn._DATA_TOUCHES[0] == t1 and p._version == v0 + 1
+    opt = torch.optim.SGD([q for q in m.parameters() if q.requires_grad], lr=0.1, momentum=0.9)
+    for q in m.parameters():
+        if q.requires_grad:
+            q.grad = torch.ones_like(q)
+    opt.step()
+    assert sn._DATA_TOUCHES[0] == t1                                    # optimiser steps do not go through .data
