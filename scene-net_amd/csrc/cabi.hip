@@ -135,10 +135,15 @@ int32_t* flag_pool_locked(int dev) {
 }
 }  // namespace
 
-int32_t* sticky_device_ptr() {
+int32_t* sticky_device_ptr(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kFlagMaxDev) return nullptr;
     if (g_sticky_dev[dev]) return g_sticky_dev[dev];   // (set once, never changed: no lock on the launch path)
+    // not allocated yet: never allocate while `stream` is capturing (hipMalloc / hipHostMalloc are illegal there and would
+    // poison the capture) -- such a launch simply has no status words to latch into (its kernel skips a null pointer)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive) return nullptr;
+    (void)hipGetLastError();
     std::lock_guard<std::mutex> lock(g_flag_mu);
     (void)flag_pool_locked(dev);
     return g_sticky_dev[dev];

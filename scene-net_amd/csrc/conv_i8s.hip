@@ -181,7 +181,7 @@ int conv_occ_i8s(const uint8_t* x, const float* bank, const float* lambdas, int 
     s.B = B; s.Z = Z; s.X = X; s.Y = Y; s.G = G; s.kz = kz; s.kx = kx;
     s.Gtot = Gtot; s.g0 = g0; s.head = head;
     s.gate = sn::current_gate();
-    s.sticky = sn::sticky_device_ptr();
+    s.sticky = sn::sticky_device_ptr(stream);
     s.nyt = (Y + TY - 1) / TY;
     // wrong-result / timing switches: -DSN_CONV_DEBUG builds only (common.h); 0 in the product
     s.dbg = sn::debug_env_int("SN_CONV_I8_DBG");
@@ -293,7 +293,7 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     z.route = route;
     z.dbg = sn::option_conv_i8z_inject_fault() ? 1 : 0;
     z.served = assume_served ? 1 : 0;
-    z.sticky = sn::sticky_device_ptr();
+    z.sticky = sn::sticky_device_ptr(stream);
     s4.sticky = z.sticky;
     z.nxt = (X + kZTX - 1) / kZTX;
     z.nyt = (Y + TY - 1) / TY;

@@ -437,7 +437,7 @@ int sn::conv_fused_lin(const uint8_t* x, const float* bank, const float* lambdas
     s.route = nullptr;
     s.prep = static_cast<const uint8_t*>(prep);
     s.served = assume_served ? 1 : 0;
-    s.sticky = sn::sticky_device_ptr();
+    s.sticky = sn::sticky_device_ptr(stream);
     if (prep) {
         // the verdict was written with the tables (at the tolerance in force then): the gated launches read it there
         s.route = s.tol > 0.0f ? reinterpret_cast<int32_t*>(const_cast<uint8_t*>(s.prep) + lin_blob_layout(s.nsteps, w24).tail_off + 4)

@@ -9,6 +9,9 @@ kernel-vs-kernel equalities in between (missing 2); the kernels are 
 
 Round 4: the loud failure path (a dependency spin that gives up, a `served` launch whose bank the guard declines: NaN outputs +
 the sticky device status) is tested on the product build through sn_set_option("conv_i8z_inject_fault")."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -603,3 +606,42 @@ def test_c3_share_32_tiles_of_128_cubed(hip_device, zwalk_variant):
     ref = go.scenenet_forward(occ[t:t + 1].cpu().double(), specs, (9, 9, 9), lambdas, last, names=names)
     assert (o_z[t:t + 1].cpu().double() - ref).abs().max().item() < TOL
     assert float(ref.max()) > 0.05
+
+
+_FIRST_LAUNCH_IN_A_CAPTURE = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from scene_net_amd import _hip
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(5)
+w = torch.rand((16, 9, 9, 9), generator=g) - 0.5
+w = w + w.flip(2); w = w + w.flip(3)
+bank = (w * torch.logspace(-2, 0.3, 16).view(16, 1, 1, 1)).float().contiguous().to(dev)
+occ = (torch.rand((2, 1, 24, 16, 64), generator=g) < 0.2).to(dev)
+lam = ((torch.rand(16, generator=g) - 0.3) / 16).to(dev)
+prep = _hip.conv_bank_prep(bank)
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):          # the library's FIRST contraction launch of this process is being captured
+    out = _hip.conv_bank(occ, bank, lam, prep=prep)[1]
+graph.replay(); torch.cuda.synchronize()
+first = out.clone()
+eager = _hip.conv_bank(occ, bank, lam, prep=prep)[1]
+graph.replay(); torch.cuda.synchronize()
+assert torch.equal(first, eager) and torch.equal(out, eager), "captured walk differs from the eager one"
+assert _hip.device_status()[0] == 0
+print("capture-first ok")
+"""
+
+
+def test_the_first_launch_of_a_process_may_be_inside_a_capture(hip_device, zwalk_variant):
+    """The device-status words are allocated lazily; a capture must never be where that happens (hipMalloc /
+    hipHostMalloc inside a capture invalidate it): a walk captured before any eager launch runs without status words,
+    and replays to the eager result."""
+    import subprocess
+    if zwalk_variant != 0:
+        pytest.skip("one fresh process is enough")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _FIRST_LAUNCH_IN_A_CAPTURE, root], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and "capture-first ok" in res.stdout, res.stdout + res.stderr
