@@ -47,6 +47,9 @@ __device__ __forceinline__ float relu_tanh(float v) {
 
 #include "conv_lin_tables.inc"   // LinShape, lin_plan, lin_tables: the per-bank work, shared with voxel.hip's rider
 
+#ifndef SN_LIN_SETS
+#define SN_LIN_SETS 2   // [measured, round 4] 3 (two steps of look-ahead, 253 VGPRs): 43.9 us against 43.4 -- the waves do not wait for latency
+#endif
 constexpr int kThreads = kLinThreads;
 constexpr int TZ = kLinTZ, TX = kLinTX, TY = kLinTY, YB = kLinYB;
 constexpr int kMaxLds = kLinMaxLds;
@@ -155,6 +158,24 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
         for (size_t i = (size_t)blockIdx.x * kThreads + tid; i < n; i += (size_t)gridDim.x * kThreads) out[i] = nan;
         if (tid == 0 && blockIdx.x == 0) sn::sticky_latch(s.sticky, 2, 0, 1);
     };
+    // The prepared table ((nsteps + 1) * 3 pieces of 1 KB: 98 KB at 9^3) arrives by LDS-DMA, every piece in flight at once.
+    // [measured, round 4, tools/lin_timing.py] the register copy it replaces -- load, wait, ds_write: 12 dependent trips to
+    // L2 per thread -- made the prologue 6.0 of the kernel's 46 us; now 3.8, of which the first tile's halo (16 loads per
+    // thread from HBM, requested first) is ~3: STREAMING the table in behind the first tile's MFMAs (eight steps per group,
+    // s_waitcnt vmcnt(0) + s_barrier gates in the loop) brought the prologue to 3.5 and cost 2 us in the loop -- 44.9 us
+    // against 43.3, removed again.
+    auto table_dma = [&]() {
+        const int pieces = (s.nsteps + 1) * 3;
+        const uint32_t at_uni = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds);
+        for (int pc = wave; pc < pieces; pc += kThreads / 64) {
+            const uint8_t* src = s.prep + (size_t)pc * 1024 + lane * 16;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(at_uni + pc * 1024);   // wave-uniform; lane l's 16 bytes land at + 16 l
+            uint32_t m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "s"(dst), "v"(src) : "memory");
+        }
+    };
     if (s.prep) {
         const LinBlob lb = lin_blob_layout(s.nsteps, kW24);
         const int32_t verdict = *reinterpret_cast<const int32_t*>(s.prep + lb.tail_off + 4);
@@ -162,8 +183,12 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             if (s.served) declined_unserved();
             return;
         }
-        const uint4* src = reinterpret_cast<const uint4*>(s.prep);
-        for (int i = tid; i < (s.nsteps + 1) * 3 * 64; i += kThreads) At[i] = src[i];
+#ifdef SN_LIN_PROLOGUE_REGS   // (the round-3 copy, for A/B runs)
+        const uint4* src4 = reinterpret_cast<const uint4*>(s.prep);
+        for (int i = tid; i < (s.nsteps + 1) * 3 * 64; i += kThreads) At[i] = src4[i];
+#else
+        table_dma();
+#endif
         if constexpr (kW24) {
             const int* ts = reinterpret_cast<const int*>(s.prep + lb.tab_off);
             for (int i = tid; i < (s.nsteps + 3) * 8; i += kThreads) offtab[i] = ts[i];
@@ -175,6 +200,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             return;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed (the barrier publishes them)
     __syncthreads();   // kstar (aliasing the halo) is dead, tables are complete
     const float scale = misc[0];
     if (SN_DBG(s, 1)) return;
@@ -278,14 +304,20 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             offA = *reinterpret_cast<const int2*>(offtab + 2 * q);
             offB = *reinterpret_cast<const int2*>(offtab + 8 + 2 * q);
         }
+        // kW24, -DSN_LIN_SETS=3: three register sets -- the operands of step st + 2 are requested before the MFMAs of step
+        // st issue.  [measured, round 4] no faster than two (43.9 against 43.4 us at C2, 253 VGPRs): the third of their time
+        // the waves of a SIMD pair are parked on the next step's reads is LDS throughput (eight waves x 13 reads a step),
+        // not latency that a longer look-ahead would cover.  Kept as a build option.
+        constexpr int kSets = kW24 ? SN_LIN_SETS : 2;
         auto load_step24 = [&](int st, uint4 (&a)[3], uint4 (&xv)[4], int2& off) {
             const uint8_t* b0 = hb + off.x;
             const uint8_t* b1 = hb + off.y;
             // (floor experiments, -DSN_CONV_DEBUG builds only, tools/debug/lin_floor.py: 32 = the A table is read for the
             // first two steps only, 64 = the halo operands likewise -- the MFMAs then run on stale registers)
             if (!(SN_DBG(s, 32) && st > 1)) {
+                const int stc = st < s.nsteps ? st : s.nsteps;   // (three sets request up to two steps past the end: the zero step)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) a[d] = At[(st * 3 + d) * 64 + lane];
+                for (int d = 0; d < 3; ++d) a[d] = At[(stc * 3 + d) * 64 + lane];
             }
             if (!(SN_DBG(s, 64) && st > 1)) {
 #pragma unroll
@@ -295,7 +327,9 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
                     xv[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
             }
-            off = *reinterpret_cast<const int2*>(offtab + 8 * (st + 2) + 2 * q);   // for this set's next use
+            // for this set's next use (kSets steps on; past the table: the zero steps' offsets, which are 0)
+            const int nx = st + kSets < s.nsteps + 2 ? st + kSets : s.nsteps + 2;
+            off = *reinterpret_cast<const int2*>(offtab + 8 * nx + 2 * q);
         };
         auto mma_step = [&](const uint4 (&a)[3], const uint4 (&xv)[4]) {
 #pragma unroll
@@ -330,6 +364,42 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
     SN_LIN_INTERLEAVE()                                                                                           \
     __builtin_amdgcn_sched_barrier(0);
         int st0 = 0;
+        if constexpr (kSets == 3) {
+            uint4 aC[3], xC[4];
+            int2 offC = *reinterpret_cast<const int2*>(offtab + 16 + 2 * q);
+            load_step24(1, aB, xB, offB);
+            __builtin_amdgcn_sched_barrier(0);
+#define SN_LIN_TRIPLE(ST)                                                                                          \
+    load_step24((ST) + 2, aC, xC, offC);                                                                          \
+    mma_step(aA, xA);                                                                                             \
+    SN_LIN_INTERLEAVE()                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    load_step24((ST) + 3, aA, xA, offA);                                                                          \
+    mma_step(aB, xB);                                                                                             \
+    SN_LIN_INTERLEAVE()                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    load_step24((ST) + 4, aB, xB, offB);                                                                          \
+    mma_step(aC, xC);                                                                                             \
+    SN_LIN_INTERLEAVE()                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define SN_EPI1(K) epi_item(std::integral_constant<int, (K)>{});
+            if (defer && nst >= 15) {   // block-uniform; the pending tile's outputs ride along the first 15 steps
+                SN_LIN_TRIPLE(0)  SN_EPI1(0) SN_EPI1(1) SN_EPI1(2)
+                SN_LIN_TRIPLE(3)  SN_EPI1(3) SN_EPI1(4) SN_EPI1(5)
+                SN_LIN_TRIPLE(6)  SN_EPI1(6) SN_EPI1(7) SN_EPI1(8)
+                SN_LIN_TRIPLE(9)  SN_EPI1(9) SN_EPI1(10) SN_EPI1(11)
+                SN_LIN_TRIPLE(12) SN_EPI1(12) SN_EPI1(13) SN_EPI1(14) SN_EPI1(15)
+                st0 = 15;
+            }
+            int st = st0;
+            for (; st + 2 < nst; st += 3) {
+                SN_LIN_TRIPLE(st)
+            }
+            if (st < nst) mma_step(aA, xA);       // one or two steps left: requested by the last triple (block-uniform)
+            if (st + 1 < nst) mma_step(aB, xB);
+#undef SN_LIN_TRIPLE
+#undef SN_EPI1
+        } else {
         if (defer && nst >= 16) {   // block-uniform; the pending tile's outputs ride along the first 16 steps
             SN_LIN_PAIR(0)  SN_EPI2(0)
             SN_LIN_PAIR(2)  SN_EPI2(2)
@@ -345,6 +415,7 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
             SN_LIN_PAIR(st)
         }
         if (nst & 1) mma_step(aA, xA);   // odd step count: the last step was loaded by the last pair (block-uniform)
+        }
 #undef SN_LIN_PAIR
 #undef SN_LIN_LOAD
 #undef SN_LIN_INTERLEAVE
