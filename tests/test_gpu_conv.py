@@ -356,6 +356,10 @@ def test_golden_forward_fused_linear(hip_device, golden_dir, tag):
     ((2, 1, 17, 17, 128), (9, 9, 9), 16),
     ((1, 1, 12, 20, 64), (11, 9, 5), 4),     # 18 x 24 = 432 halo rows: beyond the 16 register passes of 25 rows
     ((1, 1, 10, 18, 64), (9, 11, 3), 3),     # 16 x 26 = 416 halo rows
+    ((1, 1, 12, 20, 64), (17, 3, 3), 4),     # 24 x 18 = 432 halo rows, a tall kernel
+    ((1, 1, 9, 20, 64), (9, 7, 7), 3),       # the reference's sweep sizes (sweep_config.yml:50)
+    ((1, 1, 8, 12, 32), (6, 5, 5), 3),
+    ((1, 1, 8, 12, 32), (9, 6, 6), 3),       # SCENE_Net.py:30's default
 ])
 def test_fused_linear_against_oracle_and_dense_kernel(hip_device, shape, ks, G):
     torch.manual_seed(hash((shape, ks, G)) % 2**31)

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """K3L floor experiments (needs `make -B EXTRA=-DSN_CONV_DEBUG`; wrong results, timing only): SN_CONV_LIN_DBG bits 1 prologue
-only, 2 no MFMA loop, 4 no epilogue, 16 no deferral, 32 A table read for two steps only, 64 halo operands likewise -- one process per setting (the switch is read per call in debug builds)."""
+only, 2 no MFMA loop, 4 no epilogue, 16 no deferral, 32 A table read for two steps only, 64 halo operands likewise -- one process per setting (the switch is read per call in debug builds).
+CAUTION (round 4): a switch inside the software-pipelined step splits its basic block, so the debug build's own baseline is
+slower than the product (65.7 against 58.5 us with two more switches in load_step24) and a variant that replaces the
+switched code looks better than it is: "four ds_read2_b64 instead of eight ds_read_b64" read 55.6 against 67.8 here and
+44.1 against 43.3 us when built for real (tools/debug/patches/k3l_rowcells.patch).  Trust bits 1, 2, 4, 16 (whole phases)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import scene_net_amd as sna
