@@ -489,16 +489,23 @@ def main():
             out_fused = fused_step()
         torch.cuda.synchronize()
         f_ms = (time.perf_counter() - ts) / nf * 1e3
-        e0, e1 = ev(), ev()
+        e0, e1, e2 = ev(), ev(), ev()
         g_ = pipe.voxelize(batch)
         b_, l_ = model.compute_bank(dev), model.effective_lambdas(dev)
+        for _ in range(4):   # (the verdict is learnt asynchronously: after a few calls the served form runs)
+            model.fused_served(g_.occ, b_, l_, torch.float32)
+            torch.cuda.synchronize()
         e0.record()
-        for _ in range(nf):
-            sna._hip.conv_fused(g_.occ, b_, l_)
+        for _ in range(nf):   # K3L as the step runs it: prepared tables, the guard's gated launches left out
+            model.fused_served(g_.occ, b_, l_, torch.float32)
         e1.record()
+        for _ in range(nf):   # the self-contained entry: every workgroup builds the tables, gated fp32 launches behind
+            sna._hip.conv_fused(g_.occ, b_, l_)
+        e2.record()
         torch.cuda.synchronize()
         fused_info = {"ms_per_step": f_ms, "tiles_per_s_per_gpu": B / (f_ms * 1e-3),
                       "conv_launch_ms": e0.elapsed_time(e1) / nf,
+                      "conv_launch_unprepared_ms": e1.elapsed_time(e2) / nf,
                       "max_abs_diff_vs_headline_output": float((out_fused - out).abs().max()),
                       "note": "forward through linearity: one combined 24-bit kernel, Toeplitz implicit GEMM on int8 "
                               "MFMA, kernel rows packed at 24 K-bytes (0.375 MFMA/voxel instead of 3); both outputs are within 1e-4 of the fp64 reference"}

@@ -245,7 +245,11 @@ __global__ __launch_bounds__(kThreads) void conv_lin_i8_kernel(const uint8_t* __
 #define SN_EPI2(K) epi_item(std::integral_constant<int, (K)>{}); epi_item(std::integral_constant<int, (K) + 1>{});
 #ifdef SN_CONV_TIMING
     if (tid == 0) { g_lin_t[blockIdx.x * 16 + 1] = wall_clock64(); g_lin_t[blockIdx.x * 16 + 3] = 0; g_lin_t[blockIdx.x * 16 + 7] = 0; }
-    if (lane == 0) g_lin_t[blockIdx.x * 16 + 8 + wave] = 0;
+    if (lane == 0) {   // (bits 40..: HW_ID -- which SIMD the wave sits on; the busy time accumulates below)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_lin_t[blockIdx.x * 16 + 8 + wave] = (unsigned long long)(hwid & 0xffffu) << 40;
+    }
 #endif
     for (int tile = blockIdx.x; tile < s.ntiles; tile += gridDim.x) {
 #ifdef SN_CONV_TIMING

@@ -40,4 +40,19 @@ show("tile loop + last epilogue", us(t[:, 2] - t[:, 1]))
 show("  halo commit + barrier (sum)", us(t[:, 7]))
 show("end", us(t[:, 2] - t0))
 for k in range(8):
-    show(f"wave {k} busy (sum)", us(t[:, 8 + k]))
+    hw = t[:, 8 + k] >> 40          # HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
+    simd = (hw >> 4) & 3
+    show(f"wave {k} busy (sum), SIMD {np.bincount(simd, minlength=4).tolist()}", us(t[:, 8 + k] & ((1 << 40) - 1)))
+# the two waves of a SIMD: which one is the slow one?
+for sd in range(4):
+    pairs = []
+    for wg in range(n):
+        ws = [k for k in range(8) if ((t[wg, 8 + k] >> 44) & 3) == sd]
+        if len(ws) == 2:
+            a, b = (t[wg, 8 + ws[0]] & ((1 << 40) - 1)) / 100.0, (t[wg, 8 + ws[1]] & ((1 << 40) - 1)) / 100.0
+            pairs.append((ws[0], ws[1], a, b))
+    if pairs:
+        import collections
+        c = collections.Counter((p[0], p[1]) for p in pairs)
+        print(f"SIMD {sd}: wave pairs {dict(c)}; busy of the lower / higher wave id: "
+              f"{np.median([p[2] for p in pairs]):.2f} / {np.median([p[3] for p in pairs]):.2f} us")
