@@ -94,7 +94,7 @@ def _headline(isa_kernels):
 def test_audit_notices_a_ring_read_hoisted_above_the_spin(isa_kernels):
     name, body = _headline(isa_kernels)
     spin = next(i for i, l in enumerate(body) if "@zw:spin_exit" in l)
-    ring = next(i for i in range(spin, len(body)) if body[i].strip().startswith("ds_read_b128") and "offset:12288" not in body[i])
+    ring = next(i for i in range(spin, len(body)) if body[i].strip().startswith("ds_read_b128") and audit.is_ring_access(body[i]))
     line = body.pop(ring)
     claim = [i for i, l in enumerate(body) if l.strip().startswith("ds_add_rtn_u32")][1]
     body.insert(claim + 1, line)

@@ -32,8 +32,8 @@ SRC = [os.path.join(ROOT, "scene-net_amd", "csrc", f) for f in
        ("conv_i8s.hip", "conv_i8_common.inc", "conv_i8s_kernel.inc", "conv_i8f.inc", "conv_i8z.inc", "conv_prep.h",
         "conv_fp32.inc", "common.h")]
 # LDS carve-up of the walk (conv_i8z.inc): digit table, job table, scale / coefficients / bounds, counters, check table,
-# then the rings.  Offsets below kRawBase belong to tables and counters; ring and raw data start there.
-K_TABLES_END = 4 * 3 * 64 * 16 + 256 * 16 + 64 * 4 + 128 + 128 * 4 + 64 * 16   # = 18304 = 0x4780
+# the lane / ring-offset tables, then the rings.  Offsets below kRawBase belong to tables and counters; ring and raw data start there.
+K_TABLES_END = 4 * 3 * 64 * 16 + 256 * 16 + 64 * 4 + 128 + 128 * 4 + 64 * 16 + 2 * 64 * 16   # = 20352 = 0x4f80 (incl. ltab, stab)
 DEFAULT_LAUNCHED = ("Li1ELi2ELi12E",)   # sn_set_option("conv_i8z_variant") default 2: rounds of one x-row, two per ticket, 12 waves
 
 
@@ -84,7 +84,8 @@ def is_ring_access(line):
     off = ds_offset(line)
     in_tables = off is not None and 12288 <= off < K_TABLES_END
     if op.startswith(RING_OPS):
-        return not (op == "ds_read_b128" and in_tables)          # (the job table is read with ds_read_b128)
+        # (the job table, the lane table and the ring-offset table are read with ds_read_b128 / ds_read_b64)
+        return not (op in ("ds_read_b128", "ds_read_b64") and in_tables)
     if op in ("ds_read_b32", "ds_write_b32", "ds_read_b96", "ds_read2_b32"):
         return not in_tables
     return False
