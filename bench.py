@@ -300,9 +300,14 @@ def main():
     # (building one costs the host ~5-10 us, and the eager step is within 10 % of being host bound) and recorded on every
     # --event-every'th step only: [measured] round 3, 200 steps: 187.3 us/step with the records on every 4th step, 159.1 on
     # every 50th -- a record is ~2.5 us of GPU time and the host work around it starves the queue.
-    _pool = [torch.cuda.Event(enable_timing=True) for _ in range(4 * (args.steps + 8))]
+    _pool = [torch.cuda.Event(enable_timing=True) for _ in range(6 * (args.steps + 8))]
     ev = lambda: _pool.pop() if _pool else torch.cuda.Event(enable_timing=True)  # noqa: E731
-    conv_ev, vox_ev = [], []
+    conv_ev, vox_ev, conv_kev = [], [], []
+    for e_ in _pool:   # (recorded once: torch creates the hipEvent_t at the first record -- sn_launch_timing_events needs the handle)
+        e_.record()
+    # the z-walk launch can carry its own start / stop events (sn_launch_timing_events: the kernel's timestamps, what rocprofv3's
+    # kernel trace reports); every other kernel of the path is timed between two records on the stream
+    walk_events = tuple(KERNEL_SIZE) == (9, 9, 9) and args.grid % 16 == 0
 
     def step(timed):
         # K2 (GENEO bank + the int8 contraction's per-bank preparation) RIDES in K1's first launch: 16 extra workgroups of the
@@ -315,17 +320,21 @@ def main():
             a.record()
         grids = pipe.voxelize(batch, bank_rider=rider)
         if timed:
-            b.record()
-        if timed:
-            c0 = ev()
-            c0.record()
+            b.record()   # (the voxel stage's end IS the contraction's start: one record between them, not two -- a record is
+            # ~2.5 us of GPU time of its own, and the second one used to sit inside the contraction's interval)
         # (the walk's verdict for these parameters is learnt asynchronously during the warm-up; from then on the empty
         # fallback launch behind the walk is left out: scene_net.py, contract_prepared)
+        with_kev = timed and walk_events and len(vox_ev) % 2 == 0   # (every other timed step: the launch with events costs ~9 us of stream time)
+        if with_kev:
+            ks, ke = ev(), ev()
+            sna._hip.launch_timing_events(ks, ke)
+            conv_kev.append((ks, ke))
         _, out = model.contract_prepared(grids.occ, bank, lam, prep)
         if timed:
             c.record()
             vox_ev.append((a, b))
-            conv_ev.append((c0, c))
+            if not with_kev:   # (an interval that holds a launch with events is not an ordinary one)
+                conv_ev.append((b, c))
         return out
 
     def step_fp32():
@@ -400,7 +409,13 @@ def main():
         spin(step_fp32, args.spinup_ms / 4)
     dt_fp32, _ = timed_job(step_fp32, n32)
 
-    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev]))
+    conv_stream_ms = float(np.mean([a.elapsed_time(b) for a, b in conv_ev])) if conv_ev else float("nan")   # end of the voxel stage -> end of the contraction
+    conv_ms, conv_clock, conv_n = conv_stream_ms, "interval between two event records on the stream", len(conv_ev)
+    if conv_kev:
+        kms = [a.elapsed_time(b) for a, b in conv_kev]
+        if all(0.0 < k <= 1.05 * conv_stream_ms for k in kms) or not conv_ev:   # (a launch that took another kernel leaves its pair unwritten)
+            conv_ms, conv_n = float(np.mean(kms)), len(kms)
+            conv_clock = "the kernel's own start/stop timestamps (hipExtLaunchKernel events; sn_launch_timing_events)"
     vox_ms = float(np.mean([a.elapsed_time(b) for a, b in vox_ev]))
     V = args.grid ** 3
     ntaps = int(np.prod(KERNEL_SIZE))
@@ -635,7 +650,8 @@ def main():
                      "traffic": traffic.get("conv_occ_i8z_kernel" if zwalk and "conv_occ_i8z_kernel" in traffic
                                             else "conv_occ_i8f_kernel" if folded and "conv_occ_i8f_kernel" in traffic
                                             else "conv_occ_i8s_kernel" if stride4 else "conv_occ_i8_kernel"),
-                     "launch_ms": conv_ms, "launches_timed": len(conv_ev), "flops_per_launch": conv_flops, "executed": executed_tops,
+                     "launch_ms": conv_ms, "launch_clock": conv_clock, "launch_ms_between_stream_events": conv_stream_ms,
+                     "launches_timed": conv_n, "flops_per_launch": conv_flops, "executed": executed_tops,
                      "executed_frac": executed_tops / PEAK_I8_MFMA_TOPS,
                      "executed_frac_of_measured_ceiling": executed_tops / MEASURED_I8_MFMA_TOPS},
         "roofline_fp32": {"kernel": "conv_bank_kernel (K3, v_mfma_f32_16x16x4_f32; same batch, general-input path)",

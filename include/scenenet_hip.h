@@ -206,6 +206,14 @@ int sn_conv_prep_verdict_offset(void);
  * with NaN.  Synchronises the device. */
 int sn_conv_i8_spin_timeouts(unsigned long long* count);
 
+/* Measurement hook: the NEXT z-walk launch of the calling thread (sn_conv_bank_prepared[_served] on a 9^3 bank) is made with
+ * hipExtLaunchKernel(..., start_event, stop_event): the two hipEvent_t (created by the caller; either may be null) receive
+ * the kernel's own start and stop timestamps -- what a profiler's kernel trace reports -- instead of the interval between two
+ * hipEventRecord around the call, which includes the records' own ~2.5 us on the stream and the launch's dispatch.  One-shot:
+ * consumed by that launch (or by a later one if this one takes another kernel).  bench.py times the dominant kernel with it.
+ * The reference has no counterpart (its profiler is torch.profiler around core/models/SCENE_Net.py:322-339). */
+int sn_launch_timing_events(void* start_event, void* stop_event);
+
 /* The same forward output through linearity, without materialising the bank activations:
  *   relu(tanh(sum_g lambda_g conv3d(x, K_g))) == relu(tanh(conv3d(x, sum_g lambda_g K_g)))
  * (equal to 5e-16 in the reference's fp64; core/models/SCENE_Net.py:322-339).  One combined kernel

@@ -44,6 +44,7 @@ SYMBOLS = {
     "sn_conv_bank_prepared_served": (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "sn_conv_prep_verdict_offset": (c_int, []),
     "sn_conv_i8_spin_timeouts": (c_int, [_P]),
+    "sn_launch_timing_events": (c_int, [_P, _P]),
     "sn_conv_fused": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "sn_conv_fused_supported": (c_int, [_I, _I, _I, _I, _I, _I, _I]),
     "sn_forward_auto": (c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
@@ -172,6 +173,16 @@ def conv_i8_spin_timeouts() -> int:
     buf = (ctypes.c_ulonglong * 1)()
     _check(load().sn_conv_i8_spin_timeouts(ctypes.cast(buf, ctypes.c_void_p)), "sn_conv_i8_spin_timeouts")
     return int(buf[0])
+
+
+def launch_timing_events(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> None:
+    """sn_launch_timing_events: the next z-walk launch of this thread writes its own start / stop timestamps into the two
+    events (both created with enable_timing=True and RECORDED ONCE before -- torch creates the hipEvent_t at the first
+    record, and elapsed_time() wants both marked as recorded)."""
+    a, b = int(start.cuda_event), int(stop.cuda_event)
+    if not a or not b:
+        raise HipLibraryError("launch_timing_events: record each event once first (torch creates the handle lazily)")
+    _check_plain(load().sn_launch_timing_events(ctypes.c_void_p(a), ctypes.c_void_p(b)), "sn_launch_timing_events")
 
 
 def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str = "tensor") -> Optional[int]:

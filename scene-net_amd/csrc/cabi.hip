@@ -135,6 +135,15 @@ int32_t* flag_pool_locked(int dev) {
 }
 }  // namespace
 
+namespace {
+thread_local hipEvent_t g_timing_start = nullptr, g_timing_stop = nullptr;
+}
+void take_timing_events(hipEvent_t& start, hipEvent_t& stop) {
+    start = g_timing_start;
+    stop = g_timing_stop;
+    g_timing_start = g_timing_stop = nullptr;
+}
+
 int32_t* sticky_device_ptr(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kFlagMaxDev) return nullptr;
@@ -279,6 +288,12 @@ extern "C" int sn_device_status(int* code, int* detail2) {
         detail2[0] = w ? (int)w[2] : 0;
         detail2[1] = w ? (int)w[3] : 0;
     }
+    return SN_OK;
+}
+
+extern "C" int sn_launch_timing_events(void* start_event, void* stop_event) {
+    sn::g_timing_start = static_cast<hipEvent_t>(start_event);
+    sn::g_timing_stop = static_cast<hipEvent_t>(stop_event);
     return SN_OK;
 }
 

@@ -103,6 +103,7 @@ inline int debug_env_int(const char* name) {
 //   words: [0] code (0: healthy)  [1] claim (first reporter wins)  [2], [3] detail (workgroup, ticket / verdict)
 //   codes: 1 a dependency spin of the z-walk gave up;  2 a `served` launch of the z-walk declined its bank;
 //          3 a tile kernel's (folded / stride-4 / four-copy) spin gave up
+void take_timing_events(hipEvent_t& start, hipEvent_t& stop);   // cabi.hip: the pair set by sn_launch_timing_events, consumed
 int32_t* sticky_device_ptr(hipStream_t stream);   // cabi.hip: the current device's words as a DEVICE pointer (nullptr: not allocated
                                                   // and `stream` is capturing -- nothing is ever allocated inside a capture)
 int sticky_check(const char* what);   // cabi.hip: SN_OK, or SN_ERR_DEVICE_STATUS with the latched code in the error text

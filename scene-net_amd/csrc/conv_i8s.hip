@@ -32,6 +32,7 @@
 // errors), per kernel and lambda-weighted; a bank whose bound exceeds the tolerance is not run here: every
 // workgroup returns and *route = 1 sends the launch to the fp32 kernel enqueued behind this one (conv.hip).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -329,13 +330,19 @@ int conv_occ_i8z(const uint8_t* x, const float* bank, const float* lambdas, uint
     const size_t lds_4 = lds_bytes(s4), lds_f = fp32k::lds_bytes(cs, false);
     const size_t lds_fb = lds_4 > lds_f ? lds_4 : lds_f;
     if (lds > (size_t)kMaxLds || lds_fb > (size_t)kMaxLds) return 1;
+    hipEvent_t t_start = nullptr, t_stop = nullptr;
+    sn::take_timing_events(t_start, t_stop);   // (one-shot: set by sn_launch_timing_events for the next walk launch of this thread)
 #define SN_LAUNCH_I8Z(OT, KH, KR, KW)                                                                            \
     do {                                                                                                         \
         auto kern = act ? conv_occ_i8z_kernel<OT, KH, KR, KW, true> : conv_occ_i8z_kernel<OT, KH, KR, KW, false>; \
         if (sn::ensure_dynamic_lds((const void*)kern, kMaxLds) != hipSuccess)                                    \
             return check_launch("sn_conv_bank_prepared(i8z: hipFuncSetAttribute)");                              \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, stream, x, lambdas, (const uint8_t*)prep, z,       \
-                           (OT*)act, (OT*)out);                                                                  \
+        if (t_start || t_stop)   /* sn_launch_timing_events: this kernel's own start / stop timestamps */            \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), (uint32_t)lds, stream, t_start, t_stop, 0u, x, lambdas,  \
+                                  (const uint8_t*)prep, z, (OT*)act, (OT*)out);                                   \
+        else                                                                                                     \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, stream, x, lambdas, (const uint8_t*)prep, z,   \
+                               (OT*)act, (OT*)out);                                                              \
     } while (0)
 #define SN_LAUNCH_I8Z_V(KH, KR, KW)                                                                              \
     do {                                                                                                         \

@@ -645,3 +645,31 @@ def test_the_first_launch_of_a_process_may_be_inside_a_capture(hip_device, zwalk
     res = subprocess.run([sys.executable, "-c", _FIRST_LAUNCH_IN_A_CAPTURE, root], capture_output=True, text=True,
                          timeout=300)
     assert res.returncode == 0 and "capture-first ok" in res.stdout, res.stdout + res.stderr
+
+
+def test_launch_timing_events_time_the_walk_itself(hip_device, zwalk_variant):
+    """sn_launch_timing_events: the walk's own start / stop timestamps land in the caller's events (one-shot), the result is
+    untouched, and the duration is positive and no longer than the interval between two records around the call."""
+    torch.manual_seed(4)
+    occ = (torch.rand((4, 1, 64, 64, 64), device=hip_device) < 0.05)
+    bank = _symmetric_bank(16, 3).to(hip_device)
+    lam = ((torch.rand(16) - 0.3) / 16).to(hip_device)
+    prep = _hip.conv_bank_prep(bank)
+    ref = _hip.conv_bank(occ, bank, lam, prep=prep)[1]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        e.record()
+    torch.cuda.synchronize()
+    ev[0].record()
+    _hip.launch_timing_events(ev[1], ev[2])
+    out = _hip.conv_bank(occ, bank, lam, prep=prep)[1]
+    ev[3].record()
+    torch.cuda.synchronize()
+    kernel_ms, around_ms = ev[1].elapsed_time(ev[2]), ev[0].elapsed_time(ev[3])
+    assert torch.equal(out, ref)
+    assert 0.0 < kernel_ms <= around_ms, (kernel_ms, around_ms)
+    # one-shot: the next launch is an ordinary one and leaves the pair alone
+    t_before = ev[1].elapsed_time(ev[2])
+    _hip.conv_bank(occ, bank, lam, prep=prep)
+    torch.cuda.synchronize()
+    assert ev[1].elapsed_time(ev[2]) == t_before
