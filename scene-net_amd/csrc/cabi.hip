@@ -314,7 +314,7 @@ extern "C" int sn_device_status_clear(void) {
     return SN_OK;
 }
 
-extern "C" int sn_version(void) { return 103; }   // 103: round 4 (sticky device status); 102: round-3 entries (riders, sn_conv_corr_ws, sn_conv_fused_v, sn_loss_*_m / _u)
+extern "C" int sn_version(void) { return 103; }   // 103: round 4 (sticky device status, sn_launch_timing_events); 102: round-3 entries (riders, sn_conv_corr_ws, sn_conv_fused_v, sn_loss_*_m / _u)
 
 extern "C" const char* sn_last_error(void) { return sn::error_buffer(); }
 
