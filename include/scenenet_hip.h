@@ -236,8 +236,7 @@ int sn_conv_fused_v(const void* x, int x_dtype, const float* bank, const float* 
  * error bound and the Toeplitz digit tables: ~8 us that every workgroup of the kernel otherwise spends for itself -- once,
  * into a caller-owned blob of sn_conv_fused_prep_bytes(kz, kx, ky) bytes (16-byte aligned; 0: kernel extent not served),
  * and the forward on that blob: same results bit for bit.  The blob carries the guard's verdict at the tolerance in force
- * when it was written (sn_conv_fused_v's word: byte offset bytes - 12); assume_served as there.  The riders of
- * sn_voxel_occupancy_fused_bank can write the blob too (lin_prep). */
+ * when it was written (sn_conv_fused_v's word: byte offset bytes - 12); assume_served as there. */
 size_t sn_conv_fused_prep_bytes(int kz, int kx, int ky);
 int sn_conv_fused_prep(const float* bank, const float* lambdas, int G, int kz, int kx, int ky, void* blob,
                        sn_stream_t stream);

@@ -453,7 +453,7 @@ def conv_fused(x: torch.Tensor, bank: torch.Tensor, lambdas: torch.Tensor,
     B, _, Z, X, Y = x.shape
     G, kz, kx, ky = bank.shape
     out = torch.empty((B, 1, Z, X, Y), dtype=out_dtype, device=x.device)
-    if prep is not None:   # the tables come from a blob (conv_fused_prep, or the riders of the voxelisation): same bits
+    if prep is not None:   # the tables come from a blob (conv_fused_prep): same bits
         rc = load().sn_conv_fused_prepared(_ptr(x, None, "x"), _DT[x.dtype], _ptr(bank, torch.float32, "bank"),
                                            _ptr(lambdas, torch.float32, "lambdas"), _ptr(prep, torch.uint8, "prep"), B, Z,
                                            X, Y, G, kz, kx, ky, _ptr(out), _DT_OUT[out_dtype], int(bool(assume_served)),

@@ -45,7 +45,7 @@ __device__ __forceinline__ float relu_tanh(float v) {
     return (v != v) ? v : r;
 }
 
-#include "conv_lin_tables.inc"   // LinShape, lin_plan, lin_tables: the per-bank work, shared with voxel.hip's rider
+#include "conv_lin_tables.inc"   // LinShape, lin_plan, lin_tables: the per-bank work (the kernel itself and conv_lin_prep_kernel)
 
 #ifndef SN_LIN_SETS
 #define SN_LIN_SETS 2   // [measured, round 4] 3 (two steps of look-ahead, 253 VGPRs): 43.9 us against 43.4 -- the waves do not wait for latency
