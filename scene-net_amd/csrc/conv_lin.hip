@@ -45,6 +45,12 @@ __device__ __forceinline__ float relu_tanh(float v) {
     return (v != v) ? v : r;
 }
 
+#ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/lin_timing.py
+__device__ unsigned long long g_lin_t[1024 * 16];   // per workgroup: 0 start, 1 tables done, 2 end, 3 tiles, 4..6 table phases, 8.. per wave
+#define SN_LTT(k) do { if (threadIdx.x == 0) g_lin_t[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define SN_LTT(k) do {} while (0)
+#endif
 #include "conv_lin_tables.inc"   // LinShape, lin_plan, lin_tables: the per-bank work (the kernel itself and conv_lin_prep_kernel)
 
 #ifndef SN_LIN_SETS
@@ -54,9 +60,6 @@ constexpr int kThreads = kLinThreads;
 constexpr int TZ = kLinTZ, TX = kLinTX, TY = kLinTY, YB = kLinYB;
 constexpr int kMaxLds = kLinMaxLds;
 
-#ifdef SN_CONV_TIMING   // make -B EXTRA=-DSN_CONV_TIMING; read by tools/lin_timing.py
-__device__ unsigned long long g_lin_t[1024 * 16];   // per workgroup: 0 start, 1 tables done, 2 end, 3 tiles, 8.. per wave
-#endif
 // kW24: kernel rows packed at 24 bytes of K instead of 32 (ky <= 9: a 16-y strip's window is 16 + ky - 1 <= 24 bytes), 2.67
 // rows per MFMA step instead of 2: 24 % fewer steps.  K byte kappa = 24 p + o belongs to kernel row p, window byte o; a
 // lane's 16 K bytes are two 8-byte pieces pi = 8 st + 2 q + e (row pi / 3, third pi % 3), so the B operand is two

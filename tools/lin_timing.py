@@ -17,8 +17,14 @@ tiles, labels = zip(*[synthetic_tile(i, 100_000) for i in range(32)])
 batch = sna.PointBatch.from_tiles(tiles, labels, device=dev)
 pipe = sna.ScenePipeline(model, (64,) * 3, keep_labels=[15.0])
 with torch.no_grad():
-    for _ in range(5):
-        out = pipe(batch)
+    if "--unprepared" in sys.argv:   # the self-contained entry: every workgroup builds the tables (phases 4..6 are stamped there)
+        occ = pipe.voxelize(batch).occ
+        bank, lam = model.compute_bank(dev), model.effective_lambdas(dev)
+        for _ in range(5):
+            out = _hip.conv_fused(occ, bank, lam)
+    else:
+        for _ in range(5):
+            out = pipe(batch)
 torch.cuda.synchronize()
 buf = np.zeros(1024 * 16, dtype=np.uint64)
 _hip.load().sn_debug_lin_times(buf.ctypes.data_as(ctypes.c_void_p))
